@@ -1,0 +1,293 @@
+"""accelerated-ray-tracer_amd: MI355X-native render path of the reference path tracer.
+
+Python is only plumbing here (tests, bench, torch.distributed glue).  The
+product is two C libraries built from this directory:
+
+* ``lib/librt_mi355x.so``  -- HIP kernels + the C ABI of ``include/rt_abi.h``
+* ``lib/librtw_host.so``   -- host mirror of the reference's scene classes,
+  scene builders, flattener, PPM writer
+
+This module binds both with ctypes.  There is no CPU render fallback: if the
+HIP library is missing or no gfx950 device is visible, rendering raises.
+
+The directory name carries a hyphen (it follows the reference repository's
+name); import it through the ``accelerated_ray_tracer_amd`` symlink.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.realpath(__file__))
+REPO_ROOT = os.path.dirname(PKG_DIR)
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+RT_LIB_PATH = os.path.join(LIB_DIR, "librt_mi355x.so")
+HOST_LIB_PATH = os.path.join(LIB_DIR, "librtw_host.so")
+
+
+class RtError(RuntimeError):
+    pass
+
+
+# ----------------------------------------------------------------------------- structs of rt_abi.h
+class RtCamera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lower_left_corner", C.c_float * 3), ("horizontal", C.c_float * 3),
+                ("vertical", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3), ("lens_radius", C.c_float),
+                ("pad", C.c_float), ("time0", C.c_double), ("time1", C.c_double)]
+
+
+class RtSceneDesc(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_int32),
+                ("spheres", C.c_void_p), ("n_spheres", C.c_int32),
+                ("quads", C.c_void_p), ("n_quads", C.c_int32),
+                ("boxes", C.c_void_p), ("n_boxes", C.c_int32),
+                ("instances", C.c_void_p), ("n_instances", C.c_int32),
+                ("media", C.c_void_p), ("n_media", C.c_int32),
+                ("materials", C.c_void_p), ("n_materials", C.c_int32),
+                ("textures", C.c_void_p), ("n_textures", C.c_int32),
+                ("images", C.c_void_p), ("image_bytes", C.c_size_t),
+                ("camera", RtCamera)]
+
+
+class RtFrameDesc(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("ns", C.c_int32), ("gamma", C.c_float),
+                ("background", C.c_float * 3), ("use_gradient_bg", C.c_int32), ("seed_base", C.c_uint64),
+                ("tile_rows", C.c_int32), ("tile_first", C.c_int32), ("tile_stride", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RtStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("ms_render", C.c_double), ("local_rows", C.c_int32),
+                ("kernel_variant", C.c_int32), ("workgroups", C.c_int32), ("threads_per_group", C.c_int32),
+                ("lds_bytes", C.c_int32), ("reserved", C.c_int32)]
+
+
+NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("skip", "<i4"), ("bmax", "<f4", 3), ("prim", "<i4")])
+SPHERE_DTYPE = np.dtype([("c0", "<f4", 3), ("radius", "<f4"), ("vel", "<f4", 3), ("mat", "<i4")])
+MATERIAL_DTYPE = np.dtype([("kind", "<i4"), ("tex", "<i4"), ("fuzz", "<f4"), ("ior", "<f4"), ("albedo", "<f4", 3), ("pad", "<f4")])
+
+# every symbol include/rt_abi.h declares
+RT_ABI_SYMBOLS = ["rt_init", "rt_shutdown", "rt_strerror", "rt_last_hip_error", "rt_last_error_detail", "rt_scene_create",
+                  "rt_scene_destroy", "rt_frame_local_rows", "rt_local_to_global_row", "rt_render", "rt_frame_finish",
+                  "rt_set_option"]
+
+_rt = None
+_host = None
+
+
+def build(verbose: bool = False) -> None:
+    """Compile both libraries and the drop-in executable in-tree (hipcc --offload-arch=gfx950)."""
+    r = subprocess.run(["make", "-C", PKG_DIR, "-j4", "all"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise RtError("building the HIP render library failed")
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RtError(f"{HOST_LIB_PATH} not built (run __graft_entry__.build())")
+        L = C.CDLL(HOST_LIB_PATH)
+        L.rtw_last_error.restype = C.c_char_p
+        L.rtw_scene_name.restype = C.c_char_p
+        L.rtw_scene_name.argtypes = [C.c_int]
+        L.rtw_scene_build.restype = C.c_void_p
+        L.rtw_scene_build.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.rtw_scene_free.argtypes = [C.c_void_p]
+        L.rtw_scene_desc.restype = C.POINTER(RtSceneDesc)
+        L.rtw_scene_desc.argtypes = [C.c_void_p]
+        L.rtw_scene_defaults.restype = C.c_float
+        L.rtw_scene_defaults.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.rtw_scene_leaf_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.rtw_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.rtw_load_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _host = L
+    return _host
+
+
+def rt_lib():
+    """The HIP render library.  Raises when it has not been built -- there is nothing to fall back to."""
+    global _rt
+    if _rt is None:
+        if not os.path.exists(RT_LIB_PATH):
+            raise RtError(f"{RT_LIB_PATH} not built (run __graft_entry__.build()); the render path has no CPU fallback")
+        L = C.CDLL(RT_LIB_PATH)
+        L.rt_init.argtypes = [C.c_int]
+        L.rt_strerror.restype = C.c_char_p
+        L.rt_strerror.argtypes = [C.c_int]
+        L.rt_last_error_detail.restype = C.c_char_p
+        L.rt_scene_create.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(C.c_void_p)]
+        L.rt_scene_destroy.argtypes = [C.c_void_p]
+        L.rt_frame_local_rows.argtypes = [C.POINTER(RtFrameDesc)]
+        L.rt_local_to_global_row.argtypes = [C.POINTER(RtFrameDesc), C.c_int32]
+        L.rt_render.argtypes = [C.c_void_p, C.POINTER(RtFrameDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(RtStats)]
+        L.rt_frame_finish.argtypes = [C.c_void_p, C.POINTER(RtStats)]
+        L.rt_set_option.argtypes = [C.c_char_p, C.c_int]
+        _rt = L
+    return _rt
+
+
+def _check(st: int, what: str) -> None:
+    if st != 0:
+        L = rt_lib()
+        raise RtError(f"{what}: {L.rt_strerror(st).decode()} -- {L.rt_last_error_detail().decode()}")
+
+
+def load_ppm(path: str):
+    """Texture pixels from a PPM file -> (uint8 array h*w*3, w, h)."""
+    L = host_lib()
+    w, h = C.c_int(0), C.c_int(0)
+    n = L.rtw_load_ppm(path.encode(), None, 0, C.byref(w), C.byref(h))
+    if n < 0:
+        raise RtError(f"cannot read PPM {path}")
+    buf = np.zeros(n, np.uint8)
+    L.rtw_load_ppm(path.encode(), buf.ctypes.data, n, C.byref(w), C.byref(h))
+    return buf, w.value, h.value
+
+
+def default_texture():
+    """The earth map used by the reference's `earth` and `final` scenes, if the asset is present."""
+    p = os.path.join(REPO_ROOT, "assets", "earthmap.ppm")
+    return load_ppm(p) if os.path.exists(p) else (None, 0, 0)
+
+
+class HostScene:
+    """A reference scene built and flattened on the host (no GPU involved)."""
+
+    def __init__(self, name: str, nx: int = 0, ny: int = 0, image=None, iw: int = 0, ih: int = 0):
+        L = host_lib()
+        self._image = None if image is None else np.ascontiguousarray(image, np.uint8)
+        ptr = None if self._image is None else self._image.ctypes.data
+        self._h = L.rtw_scene_build(name.encode(), nx, ny, ptr, iw, ih)
+        if not self._h:
+            raise RtError(f"scene '{name}': {L.rtw_last_error().decode()}")
+        self.name = name
+        self.desc = L.rtw_scene_desc(self._h).contents
+        out4 = (C.c_int * 4)()
+        bg = (C.c_float * 3)()
+        dbl = C.c_int(0)
+        self.gamma = float(L.rtw_scene_defaults(self._h, out4, bg, C.byref(dbl)))
+        self.nx, self.ny, self.ns, self.use_gradient_bg = (int(x) for x in out4)
+        self.background = [float(x) for x in bg]
+        self.ppm_double_scale = bool(dbl.value)
+
+    def nodes(self) -> np.ndarray:
+        n = self.desc.n_nodes
+        buf = (C.c_char * (n * NODE_DTYPE.itemsize)).from_address(self.desc.nodes)
+        return np.frombuffer(buf, NODE_DTYPE, n).copy()
+
+    def spheres(self) -> np.ndarray:
+        n = self.desc.n_spheres
+        buf = (C.c_char * (n * SPHERE_DTYPE.itemsize)).from_address(self.desc.spheres)
+        return np.frombuffer(buf, SPHERE_DTYPE, n).copy()
+
+    def materials(self) -> np.ndarray:
+        n = self.desc.n_materials
+        buf = (C.c_char * (n * MATERIAL_DTYPE.itemsize)).from_address(self.desc.materials)
+        return np.frombuffer(buf, MATERIAL_DTYPE, n).copy()
+
+    def leaf_order(self) -> np.ndarray:
+        L = host_lib()
+        n = self.desc.n_nodes
+        out = np.zeros(n, np.int32)
+        L.rtw_scene_leaf_order(self._h, out.ctypes.data, n)
+        return out
+
+    def frame(self, nx=None, ny=None, ns=None, gamma=None, seed_base=1984, tile_rows=None, tile_first=0, tile_stride=1) -> RtFrameDesc:
+        f = RtFrameDesc()
+        f.nx = self.nx if nx is None else nx
+        f.ny = self.ny if ny is None else ny
+        f.ns = self.ns if ns is None else ns
+        f.gamma = self.gamma if gamma is None else gamma
+        f.background[:] = self.background
+        f.use_gradient_bg = self.use_gradient_bg
+        f.seed_base = seed_base
+        f.tile_rows = f.ny if tile_rows is None else tile_rows
+        f.tile_first = tile_first
+        f.tile_stride = tile_stride
+        return f
+
+    def close(self):
+        if getattr(self, "_h", None):
+            host_lib().rtw_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_initialised_device = None
+
+
+def init(device: int = 0) -> None:
+    global _initialised_device
+    _check(rt_lib().rt_init(device), "rt_init")
+    _initialised_device = device
+
+
+def set_option(key: str, value: int) -> None:
+    _check(rt_lib().rt_set_option(key.encode(), int(value)), f"rt_set_option({key})")
+
+
+class DeviceScene:
+    """rt_scene*: the flattened scene resident in HBM."""
+
+    def __init__(self, host_scene: HostScene):
+        if _initialised_device is None:
+            init(0)
+        self.host = host_scene
+        self._p = C.c_void_p()
+        _check(rt_lib().rt_scene_create(C.byref(host_scene.desc), C.byref(self._p)), "rt_scene_create")
+
+    def render(self, frame: RtFrameDesc, out=None, stream: int = 0, blocking: bool = True):
+        """Render into `out`: a float32 numpy array (host) or an integer device pointer.  Returns (array|None, stats)."""
+        L = rt_lib()
+        rows = L.rt_frame_local_rows(C.byref(frame))
+        if rows < 0:
+            raise RtError("bad row partition")
+        stats = RtStats()
+        if out is None:
+            out = np.empty((rows, frame.nx, 3), np.float32)
+        if isinstance(out, np.ndarray):
+            assert out.dtype == np.float32 and out.size == rows * frame.nx * 3 and out.flags["C_CONTIGUOUS"]
+            _check(L.rt_render(self._p, C.byref(frame), out.ctypes.data, 0, stream, 1, C.byref(stats)), "rt_render")
+            return out, stats
+        _check(L.rt_render(self._p, C.byref(frame), C.c_void_p(int(out)), 1, stream, 1 if blocking else 0, C.byref(stats)), "rt_render")
+        return None, stats
+
+    def finish(self) -> RtStats:
+        stats = RtStats()
+        _check(rt_lib().rt_frame_finish(self._p, C.byref(stats)), "rt_frame_finish")
+        return stats
+
+    def close(self):
+        if self._p:
+            rt_lib().rt_scene_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def local_rows_to_global(frame: RtFrameDesc) -> np.ndarray:
+    L = rt_lib()
+    rows = L.rt_frame_local_rows(C.byref(frame))
+    return np.array([L.rt_local_to_global_row(C.byref(frame), k) for k in range(rows)], np.int64)
+
+
+def write_ppm(path: str, fb: np.ndarray, double_scale: bool = False) -> None:
+    fb = np.ascontiguousarray(fb, np.float32)
+    ny, nx = fb.shape[0], fb.shape[1]
+    if host_lib().rtw_write_ppm(path.encode(), fb.ctypes.data, nx, ny, 1 if double_scale else 0) != 0:
+        raise RtError(f"cannot write {path}")

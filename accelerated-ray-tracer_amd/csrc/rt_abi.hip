@@ -1,0 +1,401 @@
+// rt_abi.hip -- implementation of include/rt_abi.h: device bookkeeping, scene
+// validation + upload, frame launch, statistics.  The kernels are in
+// rt_device.hip.  There is no CPU render path here or anywhere else in the
+// library: without a HIP device every entry point fails with
+// RT_ERR_NO_DEVICE / RT_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "rt_device.h"
+
+namespace {
+
+int g_device = -1;
+int g_num_cu = 256;
+size_t g_lds_per_cu = 160 * 1024;
+int g_last_hip_error = 0;
+std::string g_detail;
+
+// tuning knobs (rt_set_option)
+int opt_kernel = RT_KERNEL_PERSISTENT;
+int opt_lds_mode = -1;          // -1 = choose from the scene size
+int opt_steps_per_trip = 4;
+int opt_shade_threshold = 24;
+int opt_wg_per_cu = 2;
+
+// the reference's checkCudaErrors (main.cu:23-35) records "<code> at file:line 'expr'"; it then
+// exits with 99, which a library must not do, so the status is returned instead.
+#define HIPCHK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            g_last_hip_error = (int)e_;                                               \
+            char buf_[512];                                                           \
+            snprintf(buf_, sizeof(buf_), "HIP error = %u at %s:%d '%s' (%s)", (unsigned)e_, __FILE__, __LINE__, #expr, \
+                     hipGetErrorString(e_));                                          \
+            g_detail = buf_;                                                          \
+            return RT_ERR_HIP;                                                        \
+        }                                                                             \
+    } while (0)
+
+rt_status invalid(const char* why) { g_detail = why; return RT_ERR_INVALID; }
+
+template <class T>
+rt_status upload(const T* src, size_t count, const T** dst) {
+    *dst = nullptr;
+    // always allocate at least one element so kernels never see a null array base
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    bytes = (bytes + 63) & ~(size_t)63;
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes));
+    HIPCHK(hipMemset(p, 0, bytes));
+    if (count) HIPCHK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+}  // namespace
+
+struct rt_scene {
+    rt_scene_dev dev;
+    std::vector<void*> allocs;
+    bool spheres_only = false, need_uv = false;
+    int tex_level = 0;
+    size_t node_bytes = 0, sphere_bytes = 0;
+    // per-frame resources
+    unsigned long long* d_ray_counter = nullptr;
+    unsigned int* d_work_counter = nullptr;
+    float* d_fb = nullptr;
+    size_t d_fb_floats = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool frame_pending = false;
+    hipStream_t pending_stream = nullptr;
+    rt_stats pending_stats;
+};
+
+namespace {
+
+bool simple_ref_ok(const rt_scene_desc* d, int32_t ref) {
+    if (ref < 0) return false;
+    const int k = RT_PRIM_KIND(ref), i = RT_PRIM_INDEX(ref);
+    if (k == RT_PRIM_SPHERE) return i < d->n_spheres;
+    if (k == RT_PRIM_QUAD) return i < d->n_quads;
+    if (k == RT_PRIM_BOX) return i < d->n_boxes;
+    return false;
+}
+bool solid_ref_ok(const rt_scene_desc* d, int32_t ref) {
+    if (ref < 0) return false;
+    if (RT_PRIM_KIND(ref) == RT_PRIM_INSTANCE) return RT_PRIM_INDEX(ref) < d->n_instances;
+    return simple_ref_ok(d, ref);
+}
+
+// Every index a kernel will follow is checked here, on the host, so that a
+// malformed description is an error code and never a GPU fault.
+rt_status validate(const rt_scene_desc* d, bool& spheres_only, int& tex_level, bool& need_uv) {
+    if (!d) return invalid("null scene description");
+    if (d->n_nodes < 0 || d->n_spheres < 0 || d->n_quads < 0 || d->n_boxes < 0 || d->n_instances < 0 || d->n_media < 0 ||
+        d->n_materials < 0 || d->n_textures < 0)
+        return invalid("negative count");
+    if ((d->n_nodes && !d->nodes) || (d->n_spheres && !d->spheres) || (d->n_quads && !d->quads) || (d->n_boxes && !d->boxes) ||
+        (d->n_instances && !d->instances) || (d->n_media && !d->media) || (d->n_materials && !d->materials) ||
+        (d->n_textures && !d->textures) || (d->image_bytes && !d->images))
+        return invalid("null array with non-zero count");
+    if (d->n_nodes >= (1 << 28) || d->n_spheres >= (1 << 28) || d->n_quads >= (1 << 28)) return invalid("scene too large");
+    spheres_only = true;
+    for (int i = 0; i < d->n_nodes; ++i) {
+        const rt_node& n = d->nodes[i];
+        if (n.skip <= i || n.skip > d->n_nodes) return invalid("node skip link does not move forward");
+        if (n.prim >= 0) {
+            const int k = RT_PRIM_KIND(n.prim), idx = RT_PRIM_INDEX(n.prim);
+            if (k != RT_PRIM_SPHERE) spheres_only = false;
+            if (k == RT_PRIM_MEDIUM) { if (idx >= d->n_media) return invalid("medium index out of range"); }
+            else if (!solid_ref_ok(d, n.prim)) return invalid("leaf primitive reference out of range");
+        }
+    }
+    for (int i = 0; i < d->n_spheres; ++i)
+        if (d->spheres[i].mat < 0 || d->spheres[i].mat >= d->n_materials) return invalid("sphere material out of range");
+    for (int i = 0; i < d->n_quads; ++i)
+        if (d->quads[i].mat < 0 || d->quads[i].mat >= d->n_materials) return invalid("quad material out of range");
+    for (int i = 0; i < d->n_boxes; ++i)
+        if (d->boxes[i].first_quad < 0 || d->boxes[i].first_quad + 6 > d->n_quads) return invalid("box faces out of range");
+    for (int i = 0; i < d->n_instances; ++i)
+        if (!simple_ref_ok(d, d->instances[i].child)) return invalid("instance child must be a sphere, quad or box");
+    for (int i = 0; i < d->n_media; ++i) {
+        if (!solid_ref_ok(d, d->media[i].boundary)) return invalid("medium boundary must be a sphere, quad, box or instance");
+        if (d->media[i].mat < 0 || d->media[i].mat >= d->n_materials) return invalid("medium material out of range");
+    }
+    tex_level = 0; need_uv = false;
+    for (int i = 0; i < d->n_materials; ++i) {
+        const rt_material& m = d->materials[i];
+        if (m.kind < RT_MAT_LAMBERTIAN || m.kind > RT_MAT_ISOTROPIC) return invalid("unknown material kind");
+        if (m.tex >= d->n_textures) return invalid("material texture out of range");
+        if (m.tex >= 0 && tex_level < 1) tex_level = 1;
+    }
+    for (int i = 0; i < d->n_textures; ++i) {
+        const rt_texture& t = d->textures[i];
+        if (t.kind == RT_TEX_CHECKER) {
+            // even/odd must point at later-or-earlier non-self entries that terminate: forbid checker children
+            if (t.a < 0 || t.a >= d->n_textures || t.b < 0 || t.b >= d->n_textures) return invalid("checker child out of range");
+            if (d->textures[t.a].kind == RT_TEX_CHECKER || d->textures[t.b].kind == RT_TEX_CHECKER)
+                return invalid("nested checker textures are not supported");
+        } else if (t.kind == RT_TEX_IMAGE) {
+            need_uv = true; tex_level = 2;
+            if (t.a >= 0) {
+                if (t.b <= 0 || t.c <= 0) return invalid("image texture with non-positive size");
+                if ((size_t)t.a + (size_t)t.b * t.c * 3 > d->image_bytes) return invalid("image texture outside the image pool");
+            }
+        } else if (t.kind == RT_TEX_NOISE) {
+            tex_level = 2;
+        } else if (t.kind != RT_TEX_SOLID) {
+            return invalid("unknown texture kind");
+        }
+    }
+    if (d->n_quads || d->n_boxes || d->n_instances || d->n_media) spheres_only = spheres_only && false;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+rt_status rt_init(int device_ordinal) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_last_hip_error = (int)e;
+        g_detail = "no HIP device visible (the render path has no CPU fallback)";
+        return RT_ERR_NO_DEVICE;
+    }
+    if (device_ordinal < 0 || device_ordinal >= count) return invalid("device ordinal out of range");
+    HIPCHK(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_ordinal));
+    g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g_lds_per_cu = prop.maxSharedMemoryPerMultiProcessor > 0 ? (size_t)prop.maxSharedMemoryPerMultiProcessor : (size_t)160 * 1024;
+    if (!strstr(prop.gcnArchName, "gfx950")) {
+        g_detail = std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only";
+        return RT_ERR_NO_DEVICE;
+    }
+    g_device = device_ordinal;
+    return RT_OK;
+}
+
+rt_status rt_shutdown(void) {
+    g_device = -1;
+    return RT_OK;
+}
+
+const char* rt_strerror(rt_status s) {
+    switch (s) {
+    case RT_OK: return "ok";
+    case RT_ERR_INVALID: return "invalid argument or malformed scene description";
+    case RT_ERR_NO_DEVICE: return "no gfx950 HIP device";
+    case RT_ERR_HIP: return "HIP runtime error";
+    case RT_ERR_UNSUPPORTED: return "unsupported scene construct";
+    default: return "unknown status";
+    }
+}
+int rt_last_hip_error(void) { return g_last_hip_error; }
+const char* rt_last_error_detail(void) { return g_detail.c_str(); }
+
+rt_status rt_set_option(const char* key, int value) {
+    if (!key) return invalid("null option key");
+    const std::string k(key);
+    if (k == "kernel") { if (value != RT_KERNEL_PIXEL && value != RT_KERNEL_PERSISTENT) return invalid("kernel: 0 or 1"); opt_kernel = value; }
+    else if (k == "lds_mode") { if (value < -1 || value > 2) return invalid("lds_mode: -1..2"); opt_lds_mode = value; }
+    else if (k == "steps_per_trip") { if (value < 1 || value > 64) return invalid("steps_per_trip: 1..64"); opt_steps_per_trip = value; }
+    else if (k == "shade_threshold") { if (value < 1 || value > 64) return invalid("shade_threshold: 1..64"); opt_shade_threshold = value; }
+    else if (k == "wg_per_cu") { if (value < 1 || value > 8) return invalid("wg_per_cu: 1..8"); opt_wg_per_cu = value; }
+    else return invalid("unknown option");
+    return RT_OK;
+}
+
+rt_status rt_scene_destroy(rt_scene* s) {
+    if (!s) return RT_OK;
+    for (void* p : s->allocs) (void)hipFree(p);
+    if (s->d_ray_counter) (void)hipFree(s->d_ray_counter);
+    if (s->d_work_counter) (void)hipFree(s->d_work_counter);
+    if (s->d_fb) (void)hipFree(s->d_fb);
+    if (s->ev_start) (void)hipEventDestroy(s->ev_start);
+    if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
+    delete s;
+    return RT_OK;
+}
+
+rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
+    if (!out) return invalid("null output pointer");
+    *out = nullptr;
+    if (g_device < 0) { g_detail = "rt_init has not succeeded"; return RT_ERR_NO_DEVICE; }
+    bool so = false, uv = false;
+    int tx = 0;
+    rt_status st = validate(d, so, tx, uv);
+    if (st != RT_OK) return st;
+
+    rt_scene* s = new rt_scene;
+    memset(&s->dev, 0, sizeof(s->dev));
+    memset(&s->pending_stats, 0, sizeof(s->pending_stats));
+    s->spheres_only = so; s->tex_level = tx; s->need_uv = uv;
+#define UP(field, count)                                                             \
+    do {                                                                             \
+        st = upload(d->field, (size_t)(count), &s->dev.field);                       \
+        if (st != RT_OK) { rt_scene_destroy(s); return st; }                         \
+        s->allocs.push_back(const_cast<void*>(static_cast<const void*>(s->dev.field))); \
+    } while (0)
+    UP(nodes, d->n_nodes);
+    UP(spheres, d->n_spheres);
+    UP(quads, d->n_quads);
+    UP(boxes, d->n_boxes);
+    UP(instances, d->n_instances);
+    UP(media, d->n_media);
+    UP(materials, d->n_materials);
+    UP(textures, d->n_textures);
+    UP(images, d->image_bytes);
+#undef UP
+    s->dev.n_nodes = d->n_nodes;
+    s->dev.n_spheres = d->n_spheres;
+    s->dev.camera = d->camera;
+    s->node_bytes = (size_t)d->n_nodes * sizeof(rt_node);
+    s->sphere_bytes = (size_t)d->n_spheres * sizeof(rt_sphere);
+    hipError_t e;
+    if ((e = hipMalloc((void**)&s->d_ray_counter, 64)) != hipSuccess || (e = hipMalloc((void**)&s->d_work_counter, 64)) != hipSuccess ||
+        (e = hipEventCreate(&s->ev_start)) != hipSuccess || (e = hipEventCreate(&s->ev_stop)) != hipSuccess) {
+        g_last_hip_error = (int)e; g_detail = "allocating per-frame resources failed";
+        rt_scene_destroy(s);
+        return RT_ERR_HIP;
+    }
+    *out = s;
+    return RT_OK;
+}
+
+int32_t rt_frame_local_rows(const rt_frame_desc* f) {
+    if (!f || f->ny <= 0 || f->tile_rows <= 0 || f->tile_stride <= 0 || f->tile_first < 0) return -1;
+    const int n_tiles = (f->ny + f->tile_rows - 1) / f->tile_rows;
+    int rows = 0;
+    for (int t = f->tile_first; t < n_tiles; t += f->tile_stride) {
+        const int r0 = t * f->tile_rows;
+        const int r1 = r0 + f->tile_rows < f->ny ? r0 + f->tile_rows : f->ny;
+        rows += r1 - r0;
+    }
+    return rows;
+}
+
+int32_t rt_local_to_global_row(const rt_frame_desc* f, int32_t local_row) {
+    if (!f || f->tile_rows <= 0) return -1;
+    const int t = local_row / f->tile_rows;
+    return (f->tile_first + t * f->tile_stride) * f->tile_rows + (local_row - t * f->tile_rows);
+}
+
+rt_status rt_frame_finish(rt_scene* s, rt_stats* stats) {
+    if (!s) return invalid("null scene");
+    if (!s->frame_pending) { if (stats) *stats = s->pending_stats; return RT_OK; }
+    HIPCHK(hipEventSynchronize(s->ev_stop));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
+    unsigned long long rays = 0;
+    HIPCHK(hipMemcpy(&rays, s->d_ray_counter, sizeof(rays), hipMemcpyDeviceToHost));
+    s->pending_stats.ms_render = (double)ms;
+    s->pending_stats.rays = rays;
+    s->frame_pending = false;
+    if (stats) *stats = s->pending_stats;
+    return RT_OK;
+}
+
+rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_device, void* stream_v, int blocking, rt_stats* stats) {
+    if (!s || !f || !fb) return invalid("null argument");
+    if (g_device < 0) { g_detail = "rt_init has not succeeded"; return RT_ERR_NO_DEVICE; }
+    if (f->nx <= 0 || f->ny <= 0 || f->ns <= 0) return invalid("nx, ny and ns must be positive");
+    if ((long long)f->nx * f->ny >= (1ll << 31)) return invalid("frame too large");
+    const int local_rows = rt_frame_local_rows(f);
+    if (local_rows < 0) return invalid("bad row partition");
+    if (s->frame_pending) { rt_status st = rt_frame_finish(s, nullptr); if (st != RT_OK) return st; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+
+    rt_stats out;
+    memset(&out, 0, sizeof(out));
+    out.local_rows = local_rows;
+    out.samples = (uint64_t)local_rows * f->nx * f->ns;
+    if (local_rows == 0) { s->pending_stats = out; if (stats) *stats = out; return RT_OK; }
+
+    rt_frame_params fp;
+    memset(&fp, 0, sizeof(fp));
+    const size_t floats = (size_t)local_rows * f->nx * 3;
+    if (fb_on_device) fp.fb = fb;
+    else {
+        if (s->d_fb_floats < floats) {
+            if (s->d_fb) (void)hipFree(s->d_fb);
+            s->d_fb = nullptr; s->d_fb_floats = 0;
+            HIPCHK(hipMalloc((void**)&s->d_fb, floats * sizeof(float)));
+            s->d_fb_floats = floats;
+        }
+        fp.fb = s->d_fb;
+    }
+    fp.ray_counter = s->d_ray_counter;
+    fp.work_counter = s->d_work_counter;
+    fp.seed_base = f->seed_base;
+    fp.nx = f->nx; fp.ny = f->ny; fp.ns = f->ns; fp.gamma = f->gamma;
+    fp.background[0] = f->background[0]; fp.background[1] = f->background[1]; fp.background[2] = f->background[2];
+    fp.use_gradient_bg = f->use_gradient_bg;
+    fp.tile_rows = f->tile_rows; fp.tile_first = f->tile_first; fp.tile_stride = f->tile_stride;
+    fp.local_rows = local_rows;
+    fp.tiles_x = (f->nx + 7) / 8;
+    const int tiles_y = (local_rows + 7) / 8;
+    if ((long long)fp.tiles_x * tiles_y * 64 >= (1ll << 31)) return invalid("frame too large");
+    fp.work_items = (uint32_t)fp.tiles_x * (uint32_t)tiles_y * 64u;
+    fp.steps_per_trip = opt_steps_per_trip;
+    fp.shade_threshold = opt_shade_threshold;
+
+    // LDS residency: nodes + spheres if two workgroups still fit a CU, else nodes only, else none
+    int lds_mode = opt_lds_mode;
+    const size_t budget2 = g_lds_per_cu / 2 - 1024, budget1 = g_lds_per_cu - 2048;
+    if (lds_mode < 0) {
+        if (s->node_bytes + s->sphere_bytes <= budget2) lds_mode = 2;
+        else if (s->node_bytes <= budget2) lds_mode = 1;
+        else if (s->node_bytes + s->sphere_bytes <= budget1) lds_mode = 2;
+        else if (s->node_bytes <= budget1) lds_mode = 1;
+        else lds_mode = 0;
+    }
+    size_t lds_bytes = 0;
+    if (lds_mode >= 1) lds_bytes += s->node_bytes;
+    if (lds_mode >= 2) lds_bytes += s->sphere_bytes;
+    if (lds_bytes > budget1) return invalid("requested lds_mode does not fit the CU's LDS");
+
+    dim3 grid, block;
+    if (opt_kernel == RT_KERNEL_PIXEL) {
+        block = dim3(256);
+        grid = dim3((fp.work_items + 255u) / 256u);
+    } else {
+        block = dim3(RT_PERSISTENT_THREADS);
+        int per_cu = opt_wg_per_cu;
+        if (lds_bytes) { const int fit = (int)(g_lds_per_cu / (lds_bytes + 512)); if (fit < per_cu) per_cu = fit < 1 ? 1 : fit; }
+        unsigned want = (unsigned)(g_num_cu * per_cu);
+        const unsigned need = (fp.work_items + RT_PERSISTENT_THREADS - 1) / RT_PERSISTENT_THREADS;
+        grid = dim3(want < need ? want : need);
+    }
+    out.kernel_variant = opt_kernel * 1000 + lds_mode * 100 + s->tex_level * 10 + (s->spheres_only ? 1 : 0);
+    out.workgroups = (int)grid.x; out.threads_per_group = (int)block.x; out.lds_bytes = (int)lds_bytes;
+
+    HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 64, stream));
+    HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
+    HIPCHK(hipEventRecord(s->ev_start, stream));
+    rt_launch_render(opt_kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, grid, block, lds_bytes, stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev_stop, stream));
+    s->frame_pending = true;
+    s->pending_stream = stream;
+    s->pending_stats = out;
+    if (!fb_on_device) {
+        HIPCHK(hipMemcpyAsync(fb, s->d_fb, floats * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        blocking = 1;
+    }
+    if (blocking) return rt_frame_finish(s, stats);
+    if (stats) *stats = out;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// rt_device.h -- kernel argument blocks shared by rt_device.hip (kernels) and
+// rt_abi.hip (the C-ABI implementation).  Internal to librt_mi355x.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_abi.h"
+
+#define RT_PERSISTENT_THREADS 512
+
+enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_PERSISTENT = 1 };
+
+// device-resident scene: the rt_scene_desc arrays after upload
+struct rt_scene_dev {
+    const rt_node* nodes;
+    const rt_sphere* spheres;
+    const rt_quad* quads;
+    const rt_box* boxes;
+    const rt_instance* instances;
+    const rt_medium* media;
+    const rt_material* materials;
+    const rt_texture* textures;
+    const uint8_t* images;
+    int32_t n_nodes, n_spheres;
+    rt_camera camera;
+};
+
+struct rt_frame_params {
+    float* fb;                            // compact local rows, nx*3 floats each
+    unsigned long long* ray_counter;      // += rays traced
+    unsigned int* work_counter;           // persistent kernel's pixel queue head
+    uint64_t seed_base;
+    int32_t nx, ny, ns;
+    float gamma;
+    float background[3];
+    int32_t use_gradient_bg;
+    int32_t tile_rows, tile_first, tile_stride;
+    int32_t local_rows;                   // rows this call renders
+    int32_t tiles_x;                      // 8x8 pixel tiles per local row band
+    uint32_t work_items;                  // tiles_x * tiles_y * 64
+    int32_t steps_per_trip;               // persistent kernel: node visits between ballots
+    int32_t shade_threshold;              // persistent kernel: waiting lanes that trigger shading
+};
+
+void rt_launch_render(int kernel, int lds_mode, bool spheres_only, int tex_level, bool need_uv, const rt_scene_dev& sd,
+                      const rt_frame_params& fp, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream);

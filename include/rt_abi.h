@@ -1,0 +1,214 @@
+/* rt_abi.h -- C ABI of the MI355X render path (librt_mi355x.so).
+ *
+ * This is the drop-in boundary for the reference's one hot path: the kernel
+ * launches its host scene functions make (src/main.cu:685-732 and the same
+ * pattern in every scene function).  The reference has no FFI layer; what a
+ * maintainer would bind is exactly this set of entry points, each of which
+ * replaces a group of reference launches/runtime calls:
+ *
+ *   rt_init / rt_shutdown       cudaDeviceSetLimit x2 (main.cu:665-666), cudaDeviceReset (main.cu:743)
+ *   rt_scene_create             cudaMalloc(d_list|d_world|d_camera) + create_world_*<<<1,1>>>
+ *                               (main.cu:688-697); the device-heap object graph becomes flat arrays
+ *   rt_render                   cudaMallocManaged(fb) + cudaMalloc(d_rand_state) + render_init<<<>>> +
+ *                               render<<<>>> + both syncs (main.cu:676-680, 702-709)
+ *   rt_scene_destroy            free_world<<<1,1>>> + cudaFree x5 (main.cu:732-740)
+ *   rt_strerror / rt_last_hip_error   checkCudaErrors (main.cu:23-35), minus the exit(99)
+ *
+ * Plain C, plain pointers and sizes.  No C++ types, no torch types.
+ * Caller owns every rt_scene_desc array and the framebuffer; the library owns
+ * all device memory behind rt_scene*.  Not re-entrant per rt_scene*.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int rt_status;
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = 1,      /* bad argument / malformed scene description */
+    RT_ERR_NO_DEVICE = 2,    /* no gfx950 device visible */
+    RT_ERR_HIP = 3,          /* a HIP runtime call failed; see rt_last_hip_error() */
+    RT_ERR_UNSUPPORTED = 4   /* scene uses a nesting the kernels do not implement */
+};
+
+/* ---- flattened scene (what create_world_* builds with device-side new) ---- */
+
+/* primitive reference = (kind << 28) | index into that kind's array */
+enum { RT_PRIM_SPHERE = 0, RT_PRIM_QUAD = 1, RT_PRIM_BOX = 2, RT_PRIM_INSTANCE = 3, RT_PRIM_MEDIUM = 4 };
+#define RT_PRIM_REF(kind, index) ((int32_t)(((uint32_t)(kind) << 28) | (uint32_t)(index)))
+#define RT_PRIM_KIND(ref) ((int)(((uint32_t)(ref)) >> 28))
+#define RT_PRIM_INDEX(ref) ((int)(((uint32_t)(ref)) & 0x0FFFFFFFu))
+
+/* bvh_node (bvh.cuh:9-116) flattened in depth-first pre-order ("threaded"):
+ * a node whose box is hit continues at index+1 (its left child) unless it is a
+ * leaf; a node whose box is missed, and a finished leaf, continue at `skip`.
+ * prim < 0: internal node.  Every object sits in its own leaf node whose box
+ * is the object's box (the reference's n==1 node, bvh.cuh:38-43). */
+typedef struct rt_node {
+    float bmin[3];
+    int32_t skip;
+    float bmax[3];
+    int32_t prim;
+} rt_node; /* 32 B */
+
+/* sphere (sphere.cuh:10-102): centre c(t) = c0 + t*vel, vel = 0 when static */
+typedef struct rt_sphere {
+    float c0[3];
+    float radius;
+    float vel[3];
+    int32_t mat;
+} rt_sphere; /* 32 B */
+
+/* quad (quad.cuh:11-91) with its constructor-derived fields precomputed */
+typedef struct rt_quad {
+    float Q[3];
+    float D;
+    float u[3];
+    int32_t mat;
+    float v[3];
+    float pad0;
+    float w[3];
+    float pad1;
+    float n[3];
+    float pad2;
+} rt_quad; /* 80 B */
+
+/* compound6 (quad.cuh:94-143): six consecutive quads, scan order = array order */
+typedef struct rt_box {
+    int32_t first_quad;
+} rt_box;
+
+/* translate(rotate_y(child)) (hittable.cuh:40-149); either half may be absent */
+enum { RT_INST_ROTATE_Y = 1, RT_INST_TRANSLATE = 2 };
+typedef struct rt_instance {
+    float sin_t, cos_t;
+    float offset[3];
+    int32_t child;  /* prim ref: sphere, quad or box */
+    int32_t flags;
+    int32_t pad;
+} rt_instance; /* 32 B */
+
+/* constant_medium (constant_medium.cuh:16-80) */
+typedef struct rt_medium {
+    int32_t boundary; /* prim ref: sphere, quad, box or instance */
+    float neg_inv_density;
+    int32_t mat;      /* isotropic phase function */
+    int32_t pad;
+} rt_medium; /* 16 B */
+
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_DIFFUSE_LIGHT = 3, RT_MAT_ISOTROPIC = 4 };
+/* material.cuh:62-201.  tex < 0: `albedo` is the (solid) colour. */
+typedef struct rt_material {
+    int32_t kind;
+    int32_t tex;
+    float fuzz; /* metal, already clamped to <= 1 (material.cuh:97) */
+    float ior;  /* dielectric */
+    float albedo[3];
+    float pad;
+} rt_material; /* 32 B */
+
+enum { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_IMAGE = 2, RT_TEX_NOISE = 3 };
+/* texture.cuh:16-76.  checker: a/b = even/odd texture index, scale = 1/scale.
+ * image: a = byte offset into `images`, b = width, c = height (RGB8).
+ * noise: scale. */
+typedef struct rt_texture {
+    int32_t kind;
+    int32_t a, b;
+    float scale;
+    float color[3];
+    int32_t c;
+} rt_texture; /* 32 B */
+
+/* camera (camera.cuh:18-79) after init() */
+typedef struct rt_camera {
+    float origin[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3];
+    float v[3];
+    float lens_radius;
+    float pad;
+    double time0, time1;
+} rt_camera;
+
+typedef struct rt_scene_desc {
+    const rt_node* nodes;         int32_t n_nodes;
+    const rt_sphere* spheres;     int32_t n_spheres;
+    const rt_quad* quads;         int32_t n_quads;
+    const rt_box* boxes;          int32_t n_boxes;
+    const rt_instance* instances; int32_t n_instances;
+    const rt_medium* media;       int32_t n_media;
+    const rt_material* materials; int32_t n_materials;
+    const rt_texture* textures;   int32_t n_textures;
+    const uint8_t* images;        size_t image_bytes;
+    rt_camera camera;
+} rt_scene_desc;
+
+/* ---- one frame (the arguments of render<<<>>>, main.cu:107-109) ---- */
+typedef struct rt_frame_desc {
+    int32_t nx, ny;          /* full image size; pixel_index = j*nx + i, row 0 = bottom (main.cu:115) */
+    int32_t ns;              /* samples per pixel */
+    float gamma;             /* 1.0 = identity (main.cu:39) */
+    float background[3];
+    int32_t use_gradient_bg;
+    uint64_t seed_base;      /* per-pixel seed = seed_base + pixel_index (main.cu:104: 1984) */
+    /* Row partition for multi-GPU runs: the image is cut into tiles of
+     * `tile_rows` rows; this call renders tiles tile_first, tile_first +
+     * tile_stride, ...  The output buffer is compact: local row k holds global
+     * row rt_local_to_global_row(k).  Whole frame: tile_rows = ny,
+     * tile_first = 0, tile_stride = 1. */
+    int32_t tile_rows, tile_first, tile_stride;
+    int32_t reserved;
+} rt_frame_desc;
+
+typedef struct rt_stats {
+    uint64_t rays;           /* world->hit calls from color() (main.cu:57) */
+    uint64_t samples;        /* primary rays */
+    double ms_render;        /* device time of the render kernel, HIP events on the launch stream */
+    int32_t local_rows;      /* rows written by this call */
+    int32_t kernel_variant;  /* which specialisation ran */
+    int32_t workgroups, threads_per_group, lds_bytes, reserved;
+} rt_stats;
+
+typedef struct rt_scene rt_scene;
+
+rt_status rt_init(int device_ordinal);
+rt_status rt_shutdown(void);
+const char* rt_strerror(rt_status s);
+int rt_last_hip_error(void);            /* hipError_t of the last failing call, 0 if none */
+const char* rt_last_error_detail(void); /* "file:line 'expr'" of the last failure, like main.cu:28-29 */
+
+rt_status rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
+rt_status rt_scene_destroy(rt_scene* scene);
+
+/* Number of rows a frame description assigns to this call, and the mapping
+ * from a compact local row to its global row. */
+int32_t rt_frame_local_rows(const rt_frame_desc* f);
+int32_t rt_local_to_global_row(const rt_frame_desc* f, int32_t local_row);
+
+/* render_init + render (main.cu:96-133) for the rows this call owns.
+ * fb: float RGB, rt_frame_local_rows(f) * nx * 3 elements.  fb_on_device != 0:
+ * fb is device memory and the kernel writes it directly; otherwise it is host
+ * memory and the library copies the rows back.  stream: a hipStream_t (0 =
+ * default stream).  The call returns after the frame is complete when
+ * `blocking` != 0; otherwise work is only enqueued on `stream` and
+ * stats->ms_render / rays are valid after rt_frame_finish(). */
+rt_status rt_render(rt_scene* scene, const rt_frame_desc* f, float* fb, int fb_on_device,
+                    void* stream, int blocking, rt_stats* stats);
+rt_status rt_frame_finish(rt_scene* scene, rt_stats* stats);
+
+/* Tuning knobs (for A/B measurements; defaults are what ships).  Unknown keys
+ * return RT_ERR_INVALID. */
+rt_status rt_set_option(const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */
