@@ -22,11 +22,13 @@ int g_last_hip_error = 0;
 std::string g_detail;
 
 // tuning knobs (rt_set_option)
-int opt_kernel = RT_KERNEL_PERSISTENT;
+int opt_kernel = RT_KERNEL_PARKED;
 int opt_lds_mode = -1;          // -1 = choose from the scene size
-int opt_steps_per_trip = 4;
+int opt_steps_per_trip = 8;
 int opt_shade_threshold = 24;
 int opt_wg_per_cu = 2;
+int opt_leaf_threshold = 1;
+int opt_threads = RT_PERSISTENT_THREADS;
 
 // the reference's checkCudaErrors (main.cu:23-35) records "<code> at file:line 'expr'"; it then
 // exits with 99, which a library must not do, so the status is returned instead.
@@ -206,7 +208,9 @@ const char* rt_last_error_detail(void) { return g_detail.c_str(); }
 rt_status rt_set_option(const char* key, int value) {
     if (!key) return invalid("null option key");
     const std::string k(key);
-    if (k == "kernel") { if (value != RT_KERNEL_PIXEL && value != RT_KERNEL_PERSISTENT) return invalid("kernel: 0 or 1"); opt_kernel = value; }
+    if (k == "kernel") { if (value < RT_KERNEL_PIXEL || value > RT_KERNEL_PARKED) return invalid("kernel: 0, 1 or 2"); opt_kernel = value; }
+    else if (k == "leaf_threshold") { if (value < 1 || value > 64) return invalid("leaf_threshold: 1..64"); opt_leaf_threshold = value; }
+    else if (k == "threads") { if (value != 64 && value != 128 && value != 256 && value != 512) return invalid("threads: 64, 128, 256 or 512"); opt_threads = value; }
     else if (k == "lds_mode") { if (value < -1 || value > 2) return invalid("lds_mode: -1..2"); opt_lds_mode = value; }
     else if (k == "steps_per_trip") { if (value < 1 || value > 64) return invalid("steps_per_trip: 1..64"); opt_steps_per_trip = value; }
     else if (k == "shade_threshold") { if (value < 1 || value > 64) return invalid("shade_threshold: 1..64"); opt_shade_threshold = value; }
@@ -348,6 +352,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     fp.work_items = (uint32_t)fp.tiles_x * (uint32_t)tiles_y * 64u;
     fp.steps_per_trip = opt_steps_per_trip;
     fp.shade_threshold = opt_shade_threshold;
+    fp.leaf_threshold = opt_leaf_threshold;
 
     // LDS residency: nodes + spheres if two workgroups still fit a CU, else nodes only, else none
     int lds_mode = opt_lds_mode;
@@ -369,11 +374,11 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         block = dim3(256);
         grid = dim3((fp.work_items + 255u) / 256u);
     } else {
-        block = dim3(RT_PERSISTENT_THREADS);
+        block = dim3(opt_threads);
         int per_cu = opt_wg_per_cu;
         if (lds_bytes) { const int fit = (int)(g_lds_per_cu / (lds_bytes + 512)); if (fit < per_cu) per_cu = fit < 1 ? 1 : fit; }
         unsigned want = (unsigned)(g_num_cu * per_cu);
-        const unsigned need = (fp.work_items + RT_PERSISTENT_THREADS - 1) / RT_PERSISTENT_THREADS;
+        const unsigned need = (fp.work_items + opt_threads - 1) / opt_threads;
         grid = dim3(want < need ? want : need);
     }
     out.kernel_variant = opt_kernel * 1000 + lds_mode * 100 + s->tex_level * 10 + (s->spheres_only ? 1 : 0);

@@ -7,8 +7,11 @@
 #include "../../include/rt_abi.h"
 
 #define RT_PERSISTENT_THREADS 512
+#ifndef RT_PARKED_MIN_WAVES
+#define RT_PARKED_MIN_WAVES 4   // waves per SIMD the parked kernel is register-limited to allow
+#endif
 
-enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_PERSISTENT = 1 };
+enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_PERSISTENT = 1, RT_KERNEL_PARKED = 2 };
 
 // device-resident scene: the rt_scene_desc arrays after upload
 struct rt_scene_dev {
@@ -40,6 +43,7 @@ struct rt_frame_params {
     uint32_t work_items;                  // tiles_x * tiles_y * 64
     int32_t steps_per_trip;               // persistent kernel: node visits between ballots
     int32_t shade_threshold;              // persistent kernel: waiting lanes that trigger shading
+    int32_t leaf_threshold;               // parked kernel: parked lanes that trigger the leaf pass
 };
 
 void rt_launch_render(int kernel, int lds_mode, bool spheres_only, int tex_level, bool need_uv, const rt_scene_dev& sd,

@@ -712,6 +712,160 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS) rt_render_persistent_ke
     if ((threadIdx.x & 63) == 0 && rays) atomicAdd(fp.ray_counter, rays);
 }
 
+// =============================================================================
+// Kernel C ("parked"): kernel B with the leaf tests taken out of the node loop.
+//
+// Profiling kernel B (profiles/r01a_persistent_summary.txt) showed ~19 of 64
+// lanes active per VALU instruction: about one node visit in twenty is a leaf,
+// so in nearly every step some lane reaches one and the whole wave walks
+// through the object test for two or three lanes.  Here a lane whose box test
+// passes at a leaf PARKS (keeps its state, stops stepping); after the trip's
+// node steps one leaf pass serves every parked lane together.  A parked lane
+// is always served before its next box test, so each ray still sees exactly
+// the reference's sequence of tests and limits: results stay bit-identical.
+//
+// The slab test uses min/max (v_min3/v_max3) instead of the reference's
+// sign-select + ternaries.  For a finite 1/d the two forms select the same
+// values (products are never NaN, near = min(t0,t1), far = max(t0,t1), and the
+// running tmin/tmax are never NaN); a ray with a zero (or denormal-overflow)
+// direction component keeps the reference's form, chosen per trip by ballot.
+// =============================================================================
+namespace {
+// aabb::hit for rays whose 1/d components are all finite: identical result to slab_test()
+DEV bool slab_test_finite(const float4 lo_skip, const float4 hi_prim, const f3 o, const f3 inv, float tmin, float tmax) {
+    const float x0 = (lo_skip.x - o.x) * inv.x, x1 = (hi_prim.x - o.x) * inv.x;
+    const float y0 = (lo_skip.y - o.y) * inv.y, y1 = (hi_prim.y - o.y) * inv.y;
+    const float z0 = (lo_skip.z - o.z) * inv.z, z1 = (hi_prim.z - o.z) * inv.z;
+    const float nearx = fminf(x0, x1), farx = fmaxf(x0, x1);
+    const float neary = fminf(y0, y1), fary = fmaxf(y0, y1);
+    const float nearz = fminf(z0, z1), farz = fmaxf(z0, z1);
+    const float t_in = fmaxf(fmaxf(fmaxf(nearx, neary), nearz), tmin);
+    const float t_out = fminf(fminf(fminf(farx, fary), farz), tmax);
+    return !(t_out <= t_in);
+}
+DEV bool inv_is_finite(const f3 inv) {
+    return fabsf(inv.x) < INFINITY && fabsf(inv.y) < INFINITY && fabsf(inv.z) < INFINITY;
+}
+}  // namespace
+
+template <bool SPHERES_ONLY, int TEX, bool NEED_UV, int LDS_MODE>
+__global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 2) ? RT_PARKED_MIN_WAVES : 2) rt_render_parked_kernel(rt_scene_dev sd, rt_frame_params fp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const SceneView sc = stage_scene<LDS_MODE>(sd, lds);
+    const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
+    const int n_nodes = sc.n_nodes;
+    const float tmin = 0.001f;
+
+    rt_xorwow g = {0, 0, 0, 0, 0, 0};
+    int px_i = 0, px_lrow = 0, px_j = 0, sample = 0, bounce = 0;
+    f3 col = mk3(0, 0, 0), throughput = mk3(1, 1, 1), radiance = mk3(0, 0, 0);
+    Ray cur; cur.o = mk3(0, 0, 0); cur.d = mk3(0, 0, 1); cur.tm = 0.f;
+    f3 inv = mk3(1, 1, 1);
+    HitInfo best; best.t = FLT_MAX; best.prim = -1; best.inst = -1;
+    int node = n_nodes;
+    int32_t parked = -1;         // leaf primitive waiting for the leaf pass
+    bool alive = true, have_pixel = false, pending_hit = false;
+    bool finite_inv = true;
+    unsigned int rays = 0;
+
+    for (;;) {
+        // ---------------- node steps (parked and finished lanes sit out)
+        if (__ballot(!finite_inv && node < n_nodes) == 0ull) {
+            for (int step = 0; step < fp.steps_per_trip; ++step) {
+                if (node < n_nodes && parked < 0) {
+                    const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
+                    int next = __float_as_int(a.w);
+                    if (slab_test_finite(a, b, cur.o, inv, tmin, best.t)) {
+                        const int32_t prim = __float_as_int(b.w);
+                        if (prim >= 0) parked = prim;
+                        else next = node + 1;
+                    }
+                    node = next;
+                }
+            }
+        } else {   // some lane's ray has a zero direction component: the reference's own form for everyone
+            for (int step = 0; step < fp.steps_per_trip; ++step) {
+                if (node < n_nodes && parked < 0) {
+                    const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
+                    int next = __float_as_int(a.w);
+                    if (slab_test(a, b, cur.o, inv, tmin, best.t)) {
+                        const int32_t prim = __float_as_int(b.w);
+                        if (prim >= 0) parked = prim;
+                        else next = node + 1;
+                    }
+                    node = next;
+                }
+            }
+        }
+        // ---------------- leaf pass
+        const unsigned long long park_mask = __ballot(parked >= 0);
+        const unsigned long long step_mask = __ballot(node < n_nodes && parked < 0);
+        if (park_mask != 0ull && (__popcll(park_mask) >= fp.leaf_threshold || step_mask == 0ull)) {
+            if (parked >= 0) {
+                leaf_test<SPHERES_ONLY>(sc, parked, cur, tmin, best);
+                parked = -1;
+            }
+        }
+        const bool traversing = node < n_nodes || parked >= 0;
+        const bool waiting = alive && !traversing;
+        const unsigned long long wait_mask = __ballot(waiting);
+        const unsigned long long trav_mask = __ballot(traversing);
+        if (wait_mask == 0ull && trav_mask == 0ull) break;
+        if (trav_mask != 0ull && __popcll(wait_mask) < fp.shade_threshold) continue;
+
+        // ---------------- shading / regeneration block
+        if (waiting) {
+            bool need_sample = !pending_hit;
+            if (pending_hit) {
+                pending_hit = false;
+                if (best.prim < 0) {
+                    radiance = radiance + throughput * miss_color(fp, cur);
+                    need_sample = true;
+                } else {
+                    const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, best);
+                    f3 emitted, attenuation;
+                    Ray scattered;
+                    const bool go_on = shade<TEX>(sc, cur, rec, g, emitted, attenuation, scattered);
+                    radiance = radiance + throughput * emitted;
+                    ++bounce;
+                    if (!go_on || bounce >= 50) need_sample = true;
+                    else { throughput = throughput * attenuation; cur = scattered; }
+                }
+                if (need_sample) { col = col + radiance; ++sample; }
+            }
+            if (need_sample) {
+                if (have_pixel && sample >= fp.ns) { store_pixel(fp, px_i, px_lrow, col); have_pixel = false; }
+                while (!have_pixel && alive) {
+                    const uint32_t w = atomicAdd(fp.work_counter, 1u);
+                    if (w >= fp.work_items) { alive = false; break; }
+                    if (work_to_pixel(fp, w, px_i, px_lrow)) {
+                        px_j = local_to_global_row(fp, px_lrow);
+                        rt_xorwow_seed(g, fp.seed_base + (uint64_t)(px_j * fp.nx + px_i));
+                        col = mk3(0, 0, 0); sample = 0; have_pixel = true;
+                    }
+                }
+                if (alive) {
+                    const float u = ((float)px_i + rt_xorwow_uniform(g)) / (float)fp.nx;
+                    const float v = ((float)px_j + rt_xorwow_uniform(g)) / (float)fp.ny;
+                    cur = camera_get_ray(sd.camera, u, v, g);
+                    throughput = mk3(1, 1, 1); radiance = mk3(0, 0, 0); bounce = 0;
+                }
+            }
+            if (alive) {
+                inv = mk3(1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z);
+                finite_inv = inv_is_finite(inv);
+                best.t = FLT_MAX; best.prim = -1; best.inst = -1;
+                node = 0;
+                pending_hit = true;
+                ++rays;
+            }
+        }
+    }
+    unsigned long long r64 = rays;
+    for (int off = 32; off > 0; off >>= 1) r64 += __shfl_down(r64, off, 64);
+    if ((threadIdx.x & 63) == 0 && r64) atomicAdd(fp.ray_counter, r64);
+}
+
 // ------------------------------------------------------------------ launch table
 namespace {
 
@@ -721,10 +875,14 @@ void launch_variant(int kernel, const rt_scene_dev& sd, const rt_frame_params& f
         if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_render_pixel_kernel<SO, TX, UV, LM>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((rt_render_pixel_kernel<SO, TX, UV, LM>), grid, block, lds, st, sd, fp);
-    } else {
+    } else if (kernel == RT_KERNEL_PERSISTENT) {
         if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_render_persistent_kernel<SO, TX, UV, LM>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((rt_render_persistent_kernel<SO, TX, UV, LM>), grid, block, lds, st, sd, fp);
+    } else {
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_render_parked_kernel<SO, TX, UV, LM>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((rt_render_parked_kernel<SO, TX, UV, LM>), grid, block, lds, st, sd, fp);
     }
 }
 

@@ -35,6 +35,19 @@ void two_spheres(built_scene& sc) {
     sc.use_gradient_bg = 1;
 }
 
+// ---- test scene (not in the reference): vfov 0 makes every primary ray exactly (0,0,-f), so 1/d is infinite on
+// two axes, and the spheres are placed so that box faces pass through the ray origin's x and y.
+void degenerate_axes(built_scene& sc) {
+    std::vector<hittable*> objs;
+    objs.push_back(new sphere(vec3(0.5f, 0.0f, 0.0f), 0.5f, new lambertian(vec3(0.8f, 0.3f, 0.3f))));
+    objs.push_back(new sphere(vec3(-0.5f, 0.5f, 1.0f), 0.5f, new metal(vec3(0.8f, 0.8f, 0.8f), 0.3f)));
+    objs.push_back(new sphere(vec3(0.0f, -0.5f, 2.0f), 0.5f, new dielectric(1.5f)));
+    objs.push_back(new sphere(vec3(0.0f, 0.0f, -1.0f), 1.0f, new lambertian(vec3(0.3f, 0.8f, 0.3f))));
+    objs.push_back(new sphere(vec3(0.0f, -101.0f, 0.0f), 100.0f, new lambertian(vec3(0.5f, 0.5f, 0.5f))));
+    finish(sc, objs, new camera(vec3(0, 0, 5), vec3(0, 0, 0), vec3(0, 1, 0), 0.0f, aspect_of(sc.nx, sc.ny), 0.0f, 5.0f));
+    sc.use_gradient_bg = 1;
+}
+
 vec3 ut_palette(float r) {   // main.cu:149-158
     if (r < 0.25f) return vec3(1.0f, 1.0f, 1.0f);
     if (r < 0.50f) return vec3(1.0f, 0.51f, 0.0f);
@@ -258,6 +271,7 @@ struct entry {
 };
 const entry k_scenes[] = {
     {"two_spheres", two_spheres, 200, 100, 1},
+    {"degenerate", degenerate_axes, 32, 16, 8},
     {"bouncing", bouncing_spheres, 1200, 600, 10000},
     {"random_scene", bouncing_spheres, 1200, 800, 500},   // the headline frame on the reference's random scene
     {"book1", book1_random_scene, 1200, 800, 100},

@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X render path.
+
+Metric (BASELINE.json): Mrays/s (+ frame ms) on the 1200x800 random scene at 500 spp.
+A "step" is one full frame: render_init + render over every pixel (src/main.cu:96-133),
+inputs (the flattened scene) already resident in HBM.  A ray is one world->hit call from
+color() (main.cu:57), counted on the device.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU; the frame is cut into 4-row tiles dealt round-robin to the
+ranks (no cross-GPU rays, the per-pixel seed is global so pixels are identical to the
+1-GPU frame); each rank renders its rows into a compact buffer and one RCCL gather
+(torch.distributed, backend nccl) brings them to rank 0, which un-interleaves them into
+the reference's frame layout.  Total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# ALGORITHMIC bytes per ray: node, sphere and material records the
+# reference's traversal touches per ray, counted on the reference's own tree for this scene
+# (40.15 box tests x 32 B + 3.99 sphere tests x 32 B + ~1.1 material reads x 16 B).
+ALGO_BYTES_PER_RAY = {"bouncing": 1430.0, "random_scene": 1430.0, "book1": 1430.0, "cornell": 980.0, "final": 2500.0}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TILE_ROWS = 4
+
+
+class RowPlan:
+    """Interleaved row tiles: tile t (rows t*tile_rows ...) belongs to rank t % world.
+    Mirrors rt_frame_local_rows / rt_local_to_global_row of the C ABI."""
+
+    def __init__(self, ny: int, tile_rows: int, world: int):
+        self.ny, self.tile_rows, self.world = ny, tile_rows, world
+        self.n_tiles = (ny + tile_rows - 1) // tile_rows
+        self._rows = [[t * tile_rows + k for t in range(r, self.n_tiles, world) for k in range(min(tile_rows, ny - t * tile_rows))]
+                      for r in range(world)]
+        self.max_rows = max(len(g) for g in self._rows)
+
+    def rows_of(self, rank: int):
+        return self._rows[rank]
+
+
+def gather_rows(local, plan: "RowPlan", rank: int, world: int, dev):
+    """One gather of the compact per-rank row buffers to rank 0 (RCCL on GPUs, gloo in the CPU test), then the
+    un-interleave into the reference's frame layout (row 0 = bottom).  Returns the full frame on rank 0, else None."""
+    import torch
+    import torch.distributed as dist
+    gathered = [torch.zeros_like(local) for _ in range(world)] if rank == 0 else None
+    dist.gather(local, gathered, dst=0)
+    if rank != 0:
+        return None
+    full = torch.zeros((plan.ny,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+    for r in range(world):
+        idx = torch.tensor(plan.rows_of(r), dtype=torch.long, device=dev)
+        if idx.numel():
+            full.index_copy_(0, idx, gathered[r][: idx.numel()])
+    return full
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="random_scene")
+    ap.add_argument("--nx", type=int, default=1200)
+    ap.add_argument("--ny", type=int, default=800)
+    ap.add_argument("--ns", type=int, default=500)
+    ap.add_argument("--kernel", type=int, default=None, help="0 = pixel, 1 = persistent, 2 = parked (default)")
+    ap.add_argument("--opt", action="append", default=[], help="rt_set_option key=value (A/B knobs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-ns", type=int, default=16, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--save-ppm", default=None, help="write the last frame as ASCII PPM (rank 0)")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene_name: str, nx: int, ny: int, ns: int) -> dict:
+    """The oracle (a port of the reference's algorithm, see oracle/) timed on this box's host cores."""
+    import oracle
+    threads = min(os.cpu_count() or 1, 32)
+    name = "bouncing" if scene_name == "random_scene" else scene_name
+    sc = oracle.OracleScene(name, nx, ny)
+    t0 = time.time()
+    _, cnt = sc.render(ns, threads=threads, counters=True)
+    dt = time.time() - t0
+    return {"value": round(cnt["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{scene_name} {nx}x{ny} @ {ns} spp (same scene/seeds, reduced spp), {cnt['rays']} rays in {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import accelerated_ray_tracer_amd as art
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    art.init(local_rank)
+    if args.kernel is not None:
+        art.set_option("kernel", args.kernel)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        art.set_option(k, int(v))
+
+    img, iw, ih = art.default_texture()
+    hs = art.HostScene(args.scene, args.nx, args.ny, img, iw, ih)
+    ds = art.DeviceScene(hs)
+    frame = hs.frame(nx=args.nx, ny=args.ny, ns=args.ns, tile_rows=TILE_ROWS if world > 1 else args.ny,
+                     tile_first=rank if world > 1 else 0, tile_stride=world)
+    rows = art.rt_lib().rt_frame_local_rows(frame)
+    plan = RowPlan(args.ny, TILE_ROWS if world > 1 else args.ny, world)
+    assert rows == len(plan.rows_of(rank))
+    local = torch.zeros((plan.max_rows, args.nx, 3), dtype=torch.float32, device=dev)
+    full = None
+
+    stream = torch.cuda.current_stream().cuda_stream
+    kernel_ms, rays_step = [], 0
+
+    def step(record: bool):
+        nonlocal rays_step, full
+        _, st = ds.render(frame, out=local.data_ptr(), stream=stream, blocking=False)
+        if world > 1:
+            full = gather_rows(local, plan, rank, world, dev)
+        st = ds.finish()   # waits for this rank's kernel; HIP-event duration on the launch stream
+        if record:
+            kernel_ms.append(st.ms_render)
+            rays_step = st.rays
+        return st
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    r = torch.tensor([float(rays_step)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_rays = float(r.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        mrays = total_rays * args.steps / elapsed / 1e6
+        bpr = ALGO_BYTES_PER_RAY.get(args.scene, 1430.0)
+        kms = float(np.mean(kernel_ms))
+        achieved = rays_step * bpr / (kms * 1e-3) / 1e9   # GB/s, rank 0's kernel
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(f"{args.scene}_{args.nx}x{args.ny}_{args.ns}")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mrays/s, 1200x800 random scene @ 500 spp (frame ms in ms_per_step)",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene} (reference create_world_bouncing, src/main.cu:160) {args.nx}x{args.ny} @ {args.ns} spp, seed 1984+pixel",
+                       "rays_per_frame": int(total_rays), "parallelism": f"rows{world}" if world > 1 else "single",
+                       "tile_rows": TILE_ROWS if world > 1 else args.ny},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms": round(kms, 3), "algorithmic_bytes_per_ray": bpr,
+                         "note": "scene is LDS-resident: algorithmic bytes are served by LDS, not HBM (see DESIGN.md)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.scene, args.nx, args.ny, args.cpu_ns)
+        print(json.dumps(line), flush=True)
+        if args.save_ppm:
+            out = (full if world > 1 else local[: args.ny]).cpu().numpy()
+            art.write_ppm(args.save_ppm, out, hs.ppm_double_scale)
+    ds.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -675,6 +675,20 @@ void scene_two_spheres(Scene& S, int nx, int ny) {
     S.gradient = 1; S.def_nx = 200; S.def_ny = 100; S.def_ns = 1;
 }
 
+// "degenerate": not a reference scene.  vfov = 0 collapses the viewport, so every primary ray is exactly
+// (0,0,-f) from (0,0,5): 1/d is +-inf on two axes and sphere boxes are placed with faces through the ray origin's
+// x/y, which makes aabb::hit (aabb.cuh:45-61) take its 0*inf = NaN comparisons.  Used to pin the NaN semantics.
+void scene_degenerate(Scene& S, int nx, int ny) {
+    S.push(S.sphere(v3(0.5f, 0.0f, 0.0f), 0.5f, S.lambertian(v3(0.8f, 0.3f, 0.3f))));
+    S.push(S.sphere(v3(-0.5f, 0.5f, 1.0f), 0.5f, S.metal(v3(0.8f, 0.8f, 0.8f), 0.3f)));
+    S.push(S.sphere(v3(0.0f, -0.5f, 2.0f), 0.5f, S.dielectric(1.5f)));
+    S.push(S.sphere(v3(0.0f, 0.0f, -1.0f), 1.0f, S.lambertian(v3(0.3f, 0.8f, 0.3f))));
+    S.push(S.sphere(v3(0.0f, -101.0f, 0.0f), 100.0f, S.lambertian(v3(0.5f, 0.5f, 0.5f))));
+    S.finish();
+    S.cam = make_camera(v3(0, 0, 5), v3(0, 0, 0), v3(0, 1, 0), 0.0f, (float)nx / (float)ny, 0.0f, 5.0f, 0.0, 0.0);
+    S.gradient = 1; S.def_nx = 32; S.def_ny = 16; S.def_ns = 8;
+}
+
 inline V3 pick_ut_color(float r) {                                                   // main.cu:149-158
     if (r < 0.25f) return v3(1.0f, 1.0f, 1.0f);
     else if (r < 0.50f) return v3(1.0f, 0.51f, 0.0f);
@@ -922,6 +936,7 @@ int orc_scene_create(const char* name, int nx, int ny, const unsigned char* img,
     std::string n(name);
     if (img && iw > 0 && ih > 0) S->image.assign(img, img + (size_t)iw * ih * 3);
     if (n == "two_spheres") scene_two_spheres(*S, nx, ny);
+    else if (n == "degenerate") scene_degenerate(*S, nx, ny);
     else if (n == "bouncing") scene_bouncing(*S, nx, ny);
     else if (n == "book1") scene_book1(*S, nx, ny);
     else if (n == "cornell") scene_cornell(*S, nx, ny);

@@ -1,0 +1,132 @@
+"""Host logic of the product (no GPU): the reference-API mirror, BVH builder and flattener against the oracle's
+independent restatement; the C ABI surface; PPM output format."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+SCENES = [("two_spheres", 200, 100), ("bouncing", 240, 160), ("book1", 120, 80), ("cornell", 120, 120),
+          ("cornell_smoke", 120, 120), ("final", 100, 100)]
+
+
+@pytest.mark.parametrize("name,nx,ny", SCENES)
+def test_flattened_bvh_matches_oracle(art, orc, name, nx, ny):
+    hs = art.HostScene(name, nx, ny)
+    ref = orc.OracleScene(name, nx, ny).nodes()
+    n = hs.nodes()
+    assert len(n) == len(ref)
+    # boxes bit-identical, node for node, in depth-first order (bvh.cuh:29-84)
+    assert np.array_equal(n["bmin"].view(np.uint32), ref[:, 0:3].view(np.uint32))
+    assert np.array_equal(n["bmax"].view(np.uint32), ref[:, 3:6].view(np.uint32))
+    # the same object sits in every leaf
+    assert np.array_equal(hs.leaf_order(), ref[:, 6].astype(np.int32))
+    # skip links: forward, inside the array, and consistent with a pre-order walk
+    skip = n["skip"]
+    idx = np.arange(len(n))
+    assert (skip > idx).all() and (skip <= len(n)).all()
+    leaf = n["prim"] >= 0
+    assert (skip[leaf] == idx[leaf] + 1).all()
+
+
+@pytest.mark.parametrize("name,nx,ny", SCENES)
+def test_camera_matches_oracle(art, orc, name, nx, ny):
+    d = art.HostScene(name, nx, ny).desc.camera
+    mine = np.array(list(d.origin) + list(d.lower_left_corner) + list(d.horizontal) + list(d.vertical) + list(d.u) + list(d.v)
+                    + [d.lens_radius, d.time0, d.time1], np.float32)
+    assert np.array_equal(mine.view(np.uint32), orc.OracleScene(name, nx, ny).camera().view(np.uint32))
+
+
+def test_bouncing_scene_contents(art):
+    hs = art.HostScene("bouncing", 1200, 800)
+    assert hs.desc.n_spheres == 488 and hs.desc.n_nodes == 975 and hs.desc.n_quads == 0
+    m = hs.materials()
+    s = hs.spheres()
+    kinds = m["kind"][s["mat"]]
+    # 366 lambertian, 74 metal, 17 dielectric, 31 diffuse_light
+    assert [(kinds == k).sum() for k in range(4)] == [366, 74, 17, 31]
+    assert (m["fuzz"] <= 1.0).all()
+    moving = (s["vel"] != 0).any(axis=1)
+    assert moving.sum() == 395          # every small diffuse / emissive sphere moves (main.cu:191-205)
+    assert hs.use_gradient_bg == 0 and hs.gamma == pytest.approx(2.2)
+
+
+def test_reference_scene_defaults(art):
+    # what each reference host function passes to render<<<>>> (main.cu:656-661, 1074, 1130, 1179)
+    expect = {"bouncing": (1200, 600, 10000, 0), "cornell": (600, 600, 10000, 0), "cornell_smoke": (600, 600, 1000, 0),
+              "final": (800, 800, 10000, 0), "checker": (1200, 600, 500, 1), "quads": (1200, 600, 500, 1),
+              "two_spheres": (200, 100, 1, 1), "random_scene": (1200, 800, 500, 0)}
+    for name, (nx, ny, ns, grad) in expect.items():
+        hs = art.HostScene(name)
+        assert (hs.nx, hs.ny, hs.ns, hs.use_gradient_bg) == (nx, ny, ns, grad), name
+
+
+def test_unknown_scene_is_an_error(art):
+    with pytest.raises(art.RtError):
+        art.HostScene("no_such_scene")
+
+
+def test_abi_exports_every_declared_symbol(art):
+    """include/rt_abi.h <-> librt_mi355x.so: every declared function is exported (no compute call made)."""
+    hdr = open(os.path.join(art.REPO_ROOT, "include", "rt_abi.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z_]+)\s*\(", hdr)) - {"rt_scene", "rt_status"}
+    assert declared == set(art.RT_ABI_SYMBOLS), declared ^ set(art.RT_ABI_SYMBOLS)
+    L = art.rt_lib()
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.rt_strerror(0).decode() == "ok"
+
+
+def test_struct_sizes_match_header(art):
+    assert art.NODE_DTYPE.itemsize == 32 and art.SPHERE_DTYPE.itemsize == 32 and art.MATERIAL_DTYPE.itemsize == 32
+    assert C.sizeof(art.RtCamera) == 96 and C.sizeof(art.RtFrameDesc) == 56
+
+
+def test_row_partition_covers_every_row_once(art):
+    L = art.rt_lib()
+    hs = art.HostScene("two_spheres")
+    for ny, tile, world in [(800, 4, 8), (800, 4, 3), (101, 8, 4), (7, 4, 2), (600, 600, 1)]:
+        seen = []
+        for r in range(world):
+            f = hs.frame(nx=16, ny=ny, ns=1, tile_rows=tile, tile_first=r, tile_stride=world)
+            rows = art.local_rows_to_global(f)
+            assert len(rows) == L.rt_frame_local_rows(C.byref(f))
+            seen.extend(rows.tolist())
+        assert sorted(seen) == list(range(ny)), (ny, tile, world)
+
+
+def test_render_without_device_fails_loudly(art):
+    """No CPU fallback: without a GPU the product path must raise, not quietly compute something else."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(art.RtError):
+        art.init(0)
+    hs = art.HostScene("two_spheres", 16, 8)
+    with pytest.raises(art.RtError):
+        art.DeviceScene(hs)
+
+
+def test_ppm_output_format(art, tmp_path):
+    """main.cu:715-727: P3 header, rows top to bottom, int(255.99f*c) without clamping."""
+    fb = np.zeros((2, 3, 3), np.float32)
+    fb[0, 0] = [0.0, 0.5, 1.0]      # bottom-left
+    fb[1, 2] = [2.0, 0.25, 0.999]   # top-right; emitters exceed 1 and are not clamped
+    p = tmp_path / "o.ppm"
+    art.write_ppm(str(p), fb)
+    toks = p.read_text().split()
+    assert toks[:4] == ["P3", "3", "2", "255"]
+    px = np.array(toks[4:], int).reshape(2, 3, 3)
+    assert px[1, 0].tolist() == [0, 127, 255]           # last printed row is j = 0
+    assert px[0, 2].tolist() == [511, 63, 255]
+    data, w, h = art.load_ppm(str(p)) if False else (None, 0, 0)   # loader takes maxval-255 files of bytes only
+
+
+def test_ppm_texture_loader(art, tmp_path):
+    rgb = (np.arange(4 * 3 * 3) % 251).astype(np.uint8)
+    p = tmp_path / "t.ppm"
+    with open(p, "wb") as f:
+        f.write(b"P6\n# comment\n4 3\n255\n" + rgb.tobytes())
+    data, w, h = art.load_ppm(str(p))
+    assert (w, h) == (4, 3) and np.array_equal(data, rgb)

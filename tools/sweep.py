@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""A/B sweep of kernel variants / knobs in ONE process (interleaved rounds), checking that every configuration
+produces the identical frame.  Usage: sweep.py [--scene S --nx --ny --ns --rounds R] cfg1 cfg2 ...
+where cfg is comma-separated key=value rt_set_option pairs, e.g.  kernel=2,threads=256,wg_per_cu=3"""
+import argparse, os, sys, time, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import accelerated_ray_tracer_amd as art
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="random_scene"); ap.add_argument("--nx", type=int, default=1200); ap.add_argument("--ny", type=int, default=800)
+ap.add_argument("--ns", type=int, default=50); ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("cfgs", nargs="+")
+a = ap.parse_args()
+DEFAULTS = {"kernel": 2, "lds_mode": -1, "steps_per_trip": 8, "shade_threshold": 24, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512}
+art.init(0)
+img, iw, ih = art.default_texture()
+hs = art.HostScene(a.scene, a.nx, a.ny, img, iw, ih)
+ds = art.DeviceScene(hs)
+frame = hs.frame(nx=a.nx, ny=a.ny, ns=a.ns)
+buf = torch.zeros((a.ny, a.nx, 3), dtype=torch.float32, device="cuda")
+times = {c: [] for c in a.cfgs}; digest = {}; rays = {}
+for rnd in range(a.rounds):
+    for c in a.cfgs:
+        opts = dict(DEFAULTS)
+        for kv in c.split(","):
+            if kv: k, v = kv.split("="); opts[k] = int(v)
+        for k, v in opts.items(): art.set_option(k, v)
+        buf.zero_()
+        _, st = ds.render(frame, out=buf.data_ptr(), blocking=True)
+        times[c].append(st.ms_render); rays[c] = st.rays
+        if rnd == 0: digest[c] = hashlib.sha1(buf.cpu().numpy().tobytes()).hexdigest()[:12]
+ref = digest[a.cfgs[0]]
+for c in a.cfgs:
+    t = times[c]
+    print(f"{c:60s} min {min(t):9.3f} ms  med {float(np.median(t)):9.3f} ms  {rays[c]/min(t)/1e3:9.1f} Mrays/s  frame {'same' if digest[c]==ref else 'DIFFERENT '+digest[c]}", flush=True)
