@@ -22,13 +22,15 @@ int g_last_hip_error = 0;
 std::string g_detail;
 
 // tuning knobs (rt_set_option)
-int opt_kernel = RT_KERNEL_PARKED;
+int opt_kernel = RT_KERNEL_STAGED;
 int opt_lds_mode = -1;          // -1 = choose from the scene size
 int opt_steps_per_trip = 8;
 int opt_shade_threshold = 24;
 int opt_wg_per_cu = 2;
 int opt_leaf_threshold = 1;
 int opt_threads = RT_PERSISTENT_THREADS;
+int opt_diel_threshold = 4;
+int opt_newpath_threshold = 16;
 
 // the reference's checkCudaErrors (main.cu:23-35) records "<code> at file:line 'expr'"; it then
 // exits with 99, which a library must not do, so the status is returned instead.
@@ -208,8 +210,10 @@ const char* rt_last_error_detail(void) { return g_detail.c_str(); }
 rt_status rt_set_option(const char* key, int value) {
     if (!key) return invalid("null option key");
     const std::string k(key);
-    if (k == "kernel") { if (value < RT_KERNEL_PIXEL || value > RT_KERNEL_PARKED) return invalid("kernel: 0, 1 or 2"); opt_kernel = value; }
+    if (k == "kernel") { if (value < RT_KERNEL_PIXEL || value > RT_KERNEL_STAGED) return invalid("kernel: 0..3"); opt_kernel = value; }
     else if (k == "leaf_threshold") { if (value < 1 || value > 64) return invalid("leaf_threshold: 1..64"); opt_leaf_threshold = value; }
+    else if (k == "diel_threshold") { if (value < 1 || value > 64) return invalid("diel_threshold: 1..64"); opt_diel_threshold = value; }
+    else if (k == "newpath_threshold") { if (value < 1 || value > 64) return invalid("newpath_threshold: 1..64"); opt_newpath_threshold = value; }
     else if (k == "threads") { if (value != 64 && value != 128 && value != 256 && value != 512) return invalid("threads: 64, 128, 256 or 512"); opt_threads = value; }
     else if (k == "lds_mode") { if (value < -1 || value > 2) return invalid("lds_mode: -1..2"); opt_lds_mode = value; }
     else if (k == "steps_per_trip") { if (value < 1 || value > 64) return invalid("steps_per_trip: 1..64"); opt_steps_per_trip = value; }
@@ -266,7 +270,7 @@ rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->node_bytes = (size_t)d->n_nodes * sizeof(rt_node);
     s->sphere_bytes = (size_t)d->n_spheres * sizeof(rt_sphere);
     hipError_t e;
-    if ((e = hipMalloc((void**)&s->d_ray_counter, 64)) != hipSuccess || (e = hipMalloc((void**)&s->d_work_counter, 64)) != hipSuccess ||
+    if ((e = hipMalloc((void**)&s->d_ray_counter, 256)) != hipSuccess || (e = hipMalloc((void**)&s->d_work_counter, 64)) != hipSuccess ||
         (e = hipEventCreate(&s->ev_start)) != hipSuccess || (e = hipEventCreate(&s->ev_stop)) != hipSuccess) {
         g_last_hip_error = (int)e; g_detail = "allocating per-frame resources failed";
         rt_scene_destroy(s);
@@ -306,6 +310,13 @@ rt_status rt_frame_finish(rt_scene* s, rt_stats* stats) {
     s->pending_stats.rays = rays;
     s->frame_pending = false;
     if (stats) *stats = s->pending_stats;
+    return RT_OK;
+}
+
+// Diagnostic builds (-DRT_DIAG) leave per-stage execution counts behind the ray counter; 16 values.
+rt_status rt_debug_counters(rt_scene* s, unsigned long long* out16) {
+    if (!s || !out16) return invalid("null argument");
+    HIPCHK(hipMemcpy(out16, s->d_ray_counter + 1, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -353,6 +364,8 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     fp.steps_per_trip = opt_steps_per_trip;
     fp.shade_threshold = opt_shade_threshold;
     fp.leaf_threshold = opt_leaf_threshold;
+    fp.diel_threshold = opt_diel_threshold;
+    fp.newpath_threshold = opt_newpath_threshold;
 
     // LDS residency: nodes + spheres if two workgroups still fit a CU, else nodes only, else none
     int lds_mode = opt_lds_mode;
@@ -384,7 +397,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     out.kernel_variant = opt_kernel * 1000 + lds_mode * 100 + s->tex_level * 10 + (s->spheres_only ? 1 : 0);
     out.workgroups = (int)grid.x; out.threads_per_group = (int)block.x; out.lds_bytes = (int)lds_bytes;
 
-    HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 64, stream));
+    HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 256, stream));
     HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
     HIPCHK(hipEventRecord(s->ev_start, stream));
     rt_launch_render(opt_kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, grid, block, lds_bytes, stream);

@@ -11,7 +11,7 @@
 #define RT_PARKED_MIN_WAVES 4   // waves per SIMD the parked kernel is register-limited to allow
 #endif
 
-enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_PERSISTENT = 1, RT_KERNEL_PARKED = 2 };
+enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_PERSISTENT = 1, RT_KERNEL_PARKED = 2, RT_KERNEL_STAGED = 3 };
 
 // device-resident scene: the rt_scene_desc arrays after upload
 struct rt_scene_dev {
@@ -44,6 +44,8 @@ struct rt_frame_params {
     int32_t steps_per_trip;               // persistent kernel: node visits between ballots
     int32_t shade_threshold;              // persistent kernel: waiting lanes that trigger shading
     int32_t leaf_threshold;               // parked kernel: parked lanes that trigger the leaf pass
+    int32_t diel_threshold;               // staged kernel: dielectric hits that trigger their stage
+    int32_t newpath_threshold;            // staged kernel: ended paths that trigger the new-path stage
 };
 
 void rt_launch_render(int kernel, int lds_mode, bool spheres_only, int tex_level, bool need_uv, const rt_scene_dev& sd,

@@ -399,6 +399,28 @@ DEV float schlick(float cosine, float ref_idx) {
     return r0 + (1.0f - r0) * cr_pow5(1.0f - cosine);
 }
 
+// dielectric::scatter (material.cuh:119-159): direction of the scattered ray; attenuation is (1,1,1)
+DEV f3 dielectric_direction(f3 d_in, f3 n, float ior, rt_xorwow& g) {
+    f3 outward_normal;
+    const f3 reflected = reflect(d_in, n);
+    float ni_over_nt, cosine, reflect_prob;
+    f3 refracted = mk3(0.f, 0.f, 0.f);
+    const float d_n = dot(d_in, n);
+    if (d_n > 0.0f) {
+        outward_normal = -n;
+        ni_over_nt = ior;
+        cosine = d_n / length(d_in);
+        cosine = sqrtf(fmaxf(0.0f, 1.0f - ior * ior * (1.0f - cosine * cosine)));
+    } else {
+        outward_normal = n;
+        ni_over_nt = 1.0f / ior;
+        cosine = -d_n / length(d_in);
+    }
+    if (refract(d_in, outward_normal, ni_over_nt, refracted)) reflect_prob = schlick(cosine, ior);
+    else reflect_prob = 1.0f;
+    return (rt_xorwow_uniform(g) < reflect_prob) ? reflected : refracted;
+}
+
 // emitted + scatter (main.cu:71-83).  Returns false when the path ends here.
 template <int TEX>
 DEV bool shade(const SceneView& sc, const Ray& in, const HitRec& rec, rt_xorwow& g, f3& emitted, f3& attenuation, Ray& out) {
@@ -421,25 +443,8 @@ DEV bool shade(const SceneView& sc, const Ray& in, const HitRec& rec, rt_xorwow&
         return dot(out.d, rec.n) > 0.0f;
     }
     case RT_MAT_DIELECTRIC: {
-        f3 outward_normal;
-        const f3 reflected = reflect(in.d, rec.n);
-        float ni_over_nt, cosine, reflect_prob;
         attenuation = mk3(1.0f, 1.0f, 1.0f);
-        f3 refracted = mk3(0.f, 0.f, 0.f);
-        const float d_n = dot(in.d, rec.n);
-        if (d_n > 0.0f) {
-            outward_normal = -rec.n;
-            ni_over_nt = m.ior;
-            cosine = d_n / length(in.d);
-            cosine = sqrtf(fmaxf(0.0f, 1.0f - m.ior * m.ior * (1.0f - cosine * cosine)));
-        } else {
-            outward_normal = rec.n;
-            ni_over_nt = 1.0f / m.ior;
-            cosine = -d_n / length(in.d);
-        }
-        if (refract(in.d, outward_normal, ni_over_nt, refracted)) reflect_prob = schlick(cosine, m.ior);
-        else reflect_prob = 1.0f;
-        out.d = (rt_xorwow_uniform(g) < reflect_prob) ? reflected : refracted;
+        out.d = dielectric_direction(in.d, rec.n, m.ior, g);
         return true;
     }
     case RT_MAT_DIFFUSE_LIGHT: {
@@ -866,6 +871,220 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
     if ((threadIdx.x & 63) == 0 && r64) atomicAdd(fp.ray_counter, r64);
 }
 
+// =============================================================================
+// Kernel D ("staged"): kernel C with the shading block cut into stages.
+//
+// Counters for kernel C (profiles/r01_bench_n1_parked_summary.txt, pmcsweep) put
+// ~60 % of all issued VALU instructions in the shading block: ~1500
+// instructions covering every material, the dielectric path, pixel
+// finalisation and camera-ray generation, executed for ~24 waiting lanes of
+// which each needs a fraction.  A microbenchmark (tools/ubench/valu_rate.hip)
+// shows the SIMDs are close to issue-bound at ~3-4 cycles per VALU
+// wave-instruction, so instructions issued for idle lanes are the cost.
+//
+// Here a lane's state is encoded in `node`:
+//   0 <= node < n      walking the BVH (next box test)
+//   node < 0           parked at a leaf; ~node is where the walk resumes
+//   node == n + 0      traversal finished, hit/miss not yet classified
+//   node == n + 1      path ended: needs accumulate + next sample / pixel + camera ray
+//   node == n + 2      dielectric hit waiting for the (rare, long) dielectric stage
+//   node == n + 3      new ray ready, needs per-ray setup (1/d etc.)
+//   node == n + 4      no more work
+// and each stage runs when a ballot finds enough lanes for it, or when no lane
+// can walk any more.  Lambertian, metal and isotropic share one
+// random_in_unit_sphere loop.  Stages only re-order work between lanes: every
+// pixel still draws its own XORWOW stream in the reference's order.
+// =============================================================================
+// Diagnostic build only (-DRT_DIAG): per-stage execution counts, written to fp.diag (never to an output).
+#ifdef RT_DIAG
+#define DIAG_ADD(slot, value) do { const unsigned long long v_ = (unsigned long long)(value); if ((threadIdx.x & 63) == 0) diag_local[slot] += v_; } while (0)
+#else
+#define DIAG_ADD(slot, value) do { } while (0)
+#endif
+
+template <bool SPHERES_ONLY, int TEX, bool NEED_UV, int LDS_MODE>
+__global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 2) ? RT_PARKED_MIN_WAVES : 2) rt_render_staged_kernel(rt_scene_dev sd, rt_frame_params fp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef RT_DIAG
+    unsigned long long diag_local[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const SceneView sc = stage_scene<LDS_MODE>(sd, lds);
+    const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
+    const int n_nodes = sc.n_nodes;
+    const int ST_DONE = n_nodes, ST_NEWPATH = n_nodes + 1, ST_DIEL = n_nodes + 2, ST_SETUP = n_nodes + 3, ST_DEAD = n_nodes + 4;
+    const float tmin = 0.001f;
+
+    rt_xorwow g = {0, 0, 0, 0, 0, 0};
+    int px_i = 0, px_lrow = 0, px_j = 0, sample = 0, bounce = 0;
+    f3 col = mk3(0, 0, 0), throughput = mk3(1, 1, 1), radiance = mk3(0, 0, 0);
+    Ray cur; cur.o = mk3(0, 0, 0); cur.d = mk3(0, 0, 1); cur.tm = 0.f;
+    f3 inv = mk3(1, 1, 1);
+    HitInfo best; best.t = FLT_MAX; best.prim = -1; best.inst = -1;
+    int node = ST_NEWPATH;       // every lane starts by asking for a pixel
+    int32_t parked = -1;
+    bool have_pixel = false, first = true, finite_inv = true;
+    unsigned int rays = 0;
+
+    for (;;) {
+        DIAG_ADD(0, 1);
+        // ---------------- stage A: node steps
+        if (__ballot(!finite_inv && (unsigned)node < (unsigned)n_nodes) == 0ull) {
+            for (int step = 0; step < fp.steps_per_trip; ++step) {
+                DIAG_ADD(1, 1); DIAG_ADD(2, __popcll(__ballot((unsigned)node < (unsigned)n_nodes)));
+                if ((unsigned)node < (unsigned)n_nodes) {
+                    const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
+                    const bool pass = slab_test_finite(a, b, cur.o, inv, tmin, best.t);
+                    const int32_t prim = __float_as_int(b.w);
+                    const int skip = __float_as_int(a.w);
+                    const bool at_leaf = pass && prim >= 0;
+                    const int next = (pass && prim < 0) ? node + 1 : skip;
+                    parked = at_leaf ? prim : parked;
+                    node = at_leaf ? ~next : next;
+                }
+            }
+        } else {   // a lane's ray has a zero direction component: the reference's own slab form for this trip
+            for (int step = 0; step < fp.steps_per_trip; ++step) {
+                if ((unsigned)node < (unsigned)n_nodes) {
+                    const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
+                    const bool pass = slab_test(a, b, cur.o, inv, tmin, best.t);
+                    const int32_t prim = __float_as_int(b.w);
+                    const int skip = __float_as_int(a.w);
+                    const bool at_leaf = pass && prim >= 0;
+                    const int next = (pass && prim < 0) ? node + 1 : skip;
+                    parked = at_leaf ? prim : parked;
+                    node = at_leaf ? ~next : next;
+                }
+            }
+        }
+        // ---------------- stage B: leaf pass for parked lanes
+        DIAG_ADD(3, __ballot(node < 0) != 0ull); DIAG_ADD(4, __popcll(__ballot(node < 0)));
+        if (node < 0) {
+            leaf_test<SPHERES_ONLY>(sc, parked, cur, tmin, best);
+            parked = -1;
+            node = ~node;
+        }
+        const unsigned long long walking = __ballot(node < n_nodes);
+        const bool force = walking == 0ull;
+        const int n_done = __popcll(__ballot(node == ST_DONE));
+        bool ran_stage = false;
+
+        // ---------------- stage C: classify + resolve + diffuse/metal/isotropic scatter
+        if (n_done > 0 && (n_done >= fp.shade_threshold || force)) {
+            ran_stage = true;
+            DIAG_ADD(5, 1); DIAG_ADD(6, n_done);
+            DIAG_ADD(11, __popcll(__ballot(node == ST_DONE && best.prim >= 0)));
+            if (node == ST_DONE) {
+                if (best.prim < 0) {                                        // miss (main.cu:57-68)
+                    radiance = radiance + throughput * miss_color(fp, cur);
+                    node = ST_NEWPATH;
+                } else {
+                    const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, best);
+                    const rt_material m = sc.materials[rec.mat];
+                    if (m.kind == RT_MAT_DIELECTRIC) {
+                        node = ST_DIEL;
+                    } else if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
+                        const f3 emitted = (TEX > 0 && m.tex >= 0) ? texture_value<TEX>(sc, m.tex, rec.u, rec.v, rec.p) : ld3(m.albedo);
+                        radiance = radiance + throughput * emitted;         // main.cu:71, scatter() false
+                        node = ST_NEWPATH;
+                    } else {
+                        // lambertian / metal / isotropic: one shared rejection loop (material.cuh:12-18)
+                        const f3 rs = random_in_unit_sphere(g);
+                        f3 dir, attenuation;
+                        bool go_on = true;
+                        if (m.kind == RT_MAT_METAL) {                       // material.cuh:99-109
+                            const f3 reflected = reflect(unit_vector(cur.d), rec.n);
+                            dir = reflected + m.fuzz * rs;
+                            attenuation = ld3(m.albedo);
+                            go_on = dot(dir, rec.n) > 0.0f;
+                        } else {
+                            if (m.kind == RT_MAT_LAMBERTIAN) {              // material.cuh:75-86
+                                const f3 target = (rec.p + rec.n) + rs;
+                                dir = target - rec.p;
+                            } else {                                        // isotropic, material.cuh:193-200
+                                dir = rs;
+                            }
+                            attenuation = (TEX > 0 && m.tex >= 0) ? texture_value<TEX>(sc, m.tex, rec.u, rec.v, rec.p) : ld3(m.albedo);
+                        }
+                        ++bounce;
+                        if (!go_on || bounce >= 50) node = ST_NEWPATH;      // main.cu:54,76-80
+                        else {
+                            throughput = throughput * attenuation;
+                            cur.o = rec.p; cur.d = dir;                     // time carried over
+                            node = ST_SETUP;
+                        }
+                    }
+                }
+            }
+        }
+        // ---------------- stage D: dielectric scatter (material.cuh:119-159)
+        {
+            const int n_diel = __popcll(__ballot(node == ST_DIEL));
+            if (n_diel > 0 && (n_diel >= fp.diel_threshold || force)) {
+                ran_stage = true;
+                DIAG_ADD(7, 1); DIAG_ADD(8, n_diel);
+                if (node == ST_DIEL) {
+                    const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, best);
+                    const f3 dir = dielectric_direction(cur.d, rec.n, sc.materials[rec.mat].ior, g);
+                    ++bounce;
+                    if (bounce >= 50) node = ST_NEWPATH;
+                    else { throughput = throughput * mk3(1.0f, 1.0f, 1.0f); cur.o = rec.p; cur.d = dir; node = ST_SETUP; }
+                }
+            }
+        }
+        // ---------------- stage E: path end -> next sample / next pixel -> camera ray (main.cu:119-132)
+        {
+            const int n_new = __popcll(__ballot(node == ST_NEWPATH));
+            if (n_new > 0 && (n_new >= fp.newpath_threshold || force)) {
+                ran_stage = true;
+                DIAG_ADD(9, 1); DIAG_ADD(10, n_new);
+                if (node == ST_NEWPATH) {
+                    if (!first) { col = col + radiance; ++sample; }
+                    first = false;
+                    bool alive = true;
+                    if (have_pixel && sample >= fp.ns) { store_pixel(fp, px_i, px_lrow, col); have_pixel = false; }
+                    while (!have_pixel && alive) {
+                        const uint32_t w = atomicAdd(fp.work_counter, 1u);
+                        if (w >= fp.work_items) { alive = false; break; }
+                        if (work_to_pixel(fp, w, px_i, px_lrow)) {
+                            px_j = local_to_global_row(fp, px_lrow);
+                            rt_xorwow_seed(g, fp.seed_base + (uint64_t)(px_j * fp.nx + px_i));
+                            col = mk3(0, 0, 0); sample = 0; have_pixel = true;
+                        }
+                    }
+                    if (alive) {
+                        const float u = ((float)px_i + rt_xorwow_uniform(g)) / (float)fp.nx;
+                        const float v = ((float)px_j + rt_xorwow_uniform(g)) / (float)fp.ny;
+                        cur = camera_get_ray(sd.camera, u, v, g);
+                        throughput = mk3(1, 1, 1); radiance = mk3(0, 0, 0); bounce = 0;
+                        node = ST_SETUP;
+                    } else {
+                        node = ST_DEAD;
+                    }
+                }
+            }
+        }
+        // ---------------- stage F: per-ray setup
+        if (ran_stage) {
+            DIAG_ADD(12, 1); DIAG_ADD(13, __popcll(__ballot(node == ST_SETUP)));
+            if (node == ST_SETUP) {
+                inv = mk3(1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z);
+                finite_inv = inv_is_finite(inv);
+                best.t = FLT_MAX; best.prim = -1; best.inst = -1;
+                node = n_nodes > 0 ? 0 : ST_DONE;
+                ++rays;
+            }
+        } else if (force) {
+            break;   // nothing walking, nothing waiting: every lane is ST_DEAD
+        }
+    }
+    unsigned long long r64 = rays;
+    for (int off = 32; off > 0; off >>= 1) r64 += __shfl_down(r64, off, 64);
+    if ((threadIdx.x & 63) == 0 && r64) atomicAdd(fp.ray_counter, r64);
+#ifdef RT_DIAG
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 16; ++k) atomicAdd(fp.ray_counter + 1 + k, diag_local[k]);
+#endif
+}
+
 // ------------------------------------------------------------------ launch table
 namespace {
 
@@ -879,10 +1098,14 @@ void launch_variant(int kernel, const rt_scene_dev& sd, const rt_frame_params& f
         if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_render_persistent_kernel<SO, TX, UV, LM>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((rt_render_persistent_kernel<SO, TX, UV, LM>), grid, block, lds, st, sd, fp);
-    } else {
+    } else if (kernel == RT_KERNEL_PARKED) {
         if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_render_parked_kernel<SO, TX, UV, LM>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((rt_render_parked_kernel<SO, TX, UV, LM>), grid, block, lds, st, sd, fp);
+    } else {
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_render_staged_kernel<SO, TX, UV, LM>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((rt_render_staged_kernel<SO, TX, UV, LM>), grid, block, lds, st, sd, fp);
     }
 }
 

@@ -79,7 +79,7 @@ def parse():
     ap.add_argument("--nx", type=int, default=1200)
     ap.add_argument("--ny", type=int, default=800)
     ap.add_argument("--ns", type=int, default=500)
-    ap.add_argument("--kernel", type=int, default=None, help="0 = pixel, 1 = persistent, 2 = parked (default)")
+    ap.add_argument("--kernel", type=int, default=None, help="0 = pixel, 1 = persistent, 2 = parked, 3 = staged (default)")
     ap.add_argument("--opt", action="append", default=[], help="rt_set_option key=value (A/B knobs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ns", type=int, default=16, help="spp of the bounded CPU-baseline sample")

@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-4
-KERNELS = [0, 1, 2]   # pixel, persistent, parked (the default)
+KERNELS = [0, 1, 2, 3]   # pixel, persistent, parked, staged (the default)
 
 
 def assert_frames_equal(got, ref, what=""):
@@ -26,9 +26,13 @@ def assert_frames_equal(got, ref, what=""):
     assert same.all(), f"{what}: {int((~same).sum())} of {same.size} pixels are not bit-identical (max err {err})"
 
 
-def render(art, hs, kernel=2, opts=None, **frame_kw):
+DEFAULT_KERNEL = 3
+
+
+def render(art, hs, kernel=DEFAULT_KERNEL, opts=None, **frame_kw):
     art.set_option("kernel", kernel)
-    defaults = {"lds_mode": -1, "steps_per_trip": 8, "shade_threshold": 24, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512}
+    defaults = {"lds_mode": -1, "steps_per_trip": 8, "shade_threshold": 24, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512,
+                "diel_threshold": 4, "newpath_threshold": 16}
     defaults.update(opts or {})
     for k, v in defaults.items():
         art.set_option(k, v)
@@ -58,7 +62,7 @@ def test_scene_matches_oracle(gpu, orc, earth, name, nx, ny, ns):
     img, iw, ih = earth if name == "final" else (None, 0, 0)
     hs = gpu.HostScene(name, nx, ny, img, iw, ih)
     ref, cnt = orc.OracleScene(name, nx, ny, img, iw, ih).render(ns)
-    fb, st = render(gpu, hs, 2, ns=ns)
+    fb, st = render(gpu, hs, DEFAULT_KERNEL, ns=ns)
     assert st.rays == cnt["rays"], (st.rays, cnt["rays"])
     assert st.samples == nx * ny * ns
     assert_frames_equal(fb, ref, name)
@@ -81,13 +85,13 @@ def test_row_partition_is_invisible(gpu, orc):
     seed_base + global pixel index (main.cu:101-104)."""
     nx, ny, ns = 72, 50, 4
     hs = gpu.HostScene("bouncing", nx, ny)
-    whole, st_whole = render(gpu, hs, 2, ns=ns)
+    whole, st_whole = render(gpu, hs, DEFAULT_KERNEL, ns=ns)
     for tile_rows, world in [(4, 2), (4, 8), (8, 3), (1, 5), (64, 2)]:
         full = np.full((ny, nx, 3), np.nan, np.float32)
         rays = 0
         for r in range(world):
             f_kw = dict(ns=ns, tile_rows=tile_rows, tile_first=r, tile_stride=world)
-            part, st = render(gpu, hs, 2, **f_kw)
+            part, st = render(gpu, hs, DEFAULT_KERNEL, **f_kw)
             rows = gpu.local_rows_to_global(hs.frame(**f_kw))
             assert part.shape[0] == len(rows) == st.local_rows
             if len(rows):
@@ -101,7 +105,7 @@ def test_row_partition_is_invisible(gpu, orc):
 
 def test_empty_partition(gpu):
     hs = gpu.HostScene("two_spheres", 16, 4)
-    fb, st = render(gpu, hs, 2, ns=1, tile_rows=4, tile_first=3, tile_stride=4)   # only one tile exists
+    fb, st = render(gpu, hs, DEFAULT_KERNEL, ns=1, tile_rows=4, tile_first=3, tile_stride=4)   # only one tile exists
     assert fb.shape[0] == 0 and st.rays == 0 and st.local_rows == 0
 
 
@@ -109,7 +113,10 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
     """Everything the scheduler does is re-ordering: LDS residency, trip length, thresholds, workgroup shape."""
     hs = gpu.HostScene("bouncing", 128, 80)
     base, st0 = render(gpu, hs, 0, ns=6)
-    variants = [(1, {}), (2, {}), (2, {"lds_mode": 0}), (2, {"lds_mode": 1}), (1, {"lds_mode": 0}), (0, {"lds_mode": 0}),
+    variants = [(3, {}), (3, {"lds_mode": 0}), (3, {"lds_mode": 1}), (3, {"steps_per_trip": 1, "shade_threshold": 1, "diel_threshold": 1, "newpath_threshold": 1}),
+                (3, {"steps_per_trip": 11, "shade_threshold": 64, "diel_threshold": 64, "newpath_threshold": 64}), (3, {"threads": 256, "wg_per_cu": 3}),
+                (3, {"threads": 64, "wg_per_cu": 8, "shade_threshold": 40, "newpath_threshold": 3}),
+                (1, {}), (2, {}), (2, {"lds_mode": 0}), (2, {"lds_mode": 1}), (1, {"lds_mode": 0}), (0, {"lds_mode": 0}),
                 (2, {"steps_per_trip": 1}), (2, {"steps_per_trip": 13, "leaf_threshold": 40}), (2, {"shade_threshold": 1}),
                 (2, {"shade_threshold": 64, "leaf_threshold": 64}), (2, {"threads": 256, "wg_per_cu": 3}), (2, {"threads": 64, "wg_per_cu": 8}),
                 (1, {"threads": 128, "steps_per_trip": 3, "shade_threshold": 7})]
@@ -119,7 +126,7 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
         assert np.array_equal(fb.view(np.uint32), base.view(np.uint32)), (kernel, opts)
     hs2 = gpu.HostScene("cornell_smoke", 48, 48)
     base2, _ = render(gpu, hs2, 0, ns=4)
-    for kernel, opts in [(2, {}), (2, {"lds_mode": 0}), (1, {"lds_mode": 1}), (2, {"steps_per_trip": 2, "shade_threshold": 60})]:
+    for kernel, opts in [(3, {}), (3, {"lds_mode": 0, "diel_threshold": 1}), (2, {}), (2, {"lds_mode": 0}), (1, {"lds_mode": 1}), (2, {"steps_per_trip": 2, "shade_threshold": 60})]:
         fb, _ = render(gpu, hs2, kernel, opts, ns=4)
         assert np.array_equal(fb.view(np.uint32), base2.view(np.uint32)), (kernel, opts)
 
@@ -129,12 +136,12 @@ def test_headline_frame_properties(gpu, orc):
     sensitivity, no NaN, exact ray count per sample band -- plus the oracle on a band of rows."""
     nx, ny, ns = 1200, 800, 10
     hs = gpu.HostScene("random_scene", nx, ny)
-    a, st_a = render(gpu, hs, 2, ns=ns)
-    b, st_b = render(gpu, hs, 2, ns=ns)
+    a, st_a = render(gpu, hs, DEFAULT_KERNEL, ns=ns)
+    b, st_b = render(gpu, hs, DEFAULT_KERNEL, ns=ns)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and st_a.rays == st_b.rays      # idempotent
     c, st_c = render(gpu, hs, 0, ns=ns)
     assert np.array_equal(a.view(np.uint32), c.view(np.uint32)) and st_a.rays == st_c.rays      # scheduling-independent
-    d, _ = render(gpu, hs, 2, ns=ns, seed_base=2024)
+    d, _ = render(gpu, hs, DEFAULT_KERNEL, ns=ns, seed_base=2024)
     assert not np.array_equal(a, d)                                                             # the seed matters
     assert not np.isnan(a).any() and (a >= 0).all()
     rps = st_a.rays / st_a.samples
@@ -142,7 +149,7 @@ def test_headline_frame_properties(gpu, orc):
     o = orc.OracleScene("bouncing", nx, ny)
     ref, cnt = o.render(ns, row0=400, row1=408)
     assert_frames_equal(a[400:408], ref[400:408], "rows 400..407 of the headline frame")
-    band, st_band = render(gpu, hs, 2, ns=ns, tile_rows=8, tile_first=400 // 8, tile_stride=10 ** 6)
+    band, st_band = render(gpu, hs, DEFAULT_KERNEL, ns=ns, tile_rows=8, tile_first=400 // 8, tile_stride=10 ** 6)
     assert np.array_equal(band.view(np.uint32), a[400:408].view(np.uint32))
     assert st_band.rays == cnt["rays"]
 
@@ -151,7 +158,7 @@ def test_device_pointer_output(gpu):
     """The boundary also takes a device pointer (what bench.py and a multi-GPU caller pass)."""
     import torch
     hs = gpu.HostScene("cornell", 40, 40)
-    host, st = render(gpu, hs, 2, ns=3)
+    host, st = render(gpu, hs, DEFAULT_KERNEL, ns=3)
     ds = gpu.DeviceScene(hs)
     buf = torch.zeros((40, 40, 3), dtype=torch.float32, device="cuda")
     s = torch.cuda.Stream()
