@@ -31,6 +31,10 @@ int opt_leaf_threshold = 1;
 int opt_threads = RT_PERSISTENT_THREADS;
 int opt_diel_threshold = 4;
 int opt_newpath_threshold = 16;
+int opt_wf_slots = 0;            // 0 = as many as fit in LDS (<= 1024)
+int opt_wf_pause_lanes = 32;
+int opt_wf_threads = 512;
+int opt_wf_wg_per_cu = 1;
 
 // the reference's checkCudaErrors (main.cu:23-35) records "<code> at file:line 'expr'"; it then
 // exits with 99, which a library must not do, so the status is returned instead.
@@ -210,10 +214,14 @@ const char* rt_last_error_detail(void) { return g_detail.c_str(); }
 rt_status rt_set_option(const char* key, int value) {
     if (!key) return invalid("null option key");
     const std::string k(key);
-    if (k == "kernel") { if (value < RT_KERNEL_PIXEL || value > RT_KERNEL_STAGED) return invalid("kernel: 0..3"); opt_kernel = value; }
+    if (k == "kernel") { if (value < RT_KERNEL_PIXEL || value > RT_KERNEL_WAVEFRONT) return invalid("kernel: 0..4"); opt_kernel = value; }
     else if (k == "leaf_threshold") { if (value < 1 || value > 64) return invalid("leaf_threshold: 1..64"); opt_leaf_threshold = value; }
     else if (k == "diel_threshold") { if (value < 1 || value > 64) return invalid("diel_threshold: 1..64"); opt_diel_threshold = value; }
     else if (k == "newpath_threshold") { if (value < 1 || value > 64) return invalid("newpath_threshold: 1..64"); opt_newpath_threshold = value; }
+    else if (k == "wf_slots") { if (value < 0 || value > 4096 || (value % 64)) return invalid("wf_slots: 0 or a multiple of 64 up to 4096"); opt_wf_slots = value; }
+    else if (k == "wf_threads") { if (value != 256 && value != 512 && value != 768 && value != 1024) return invalid("wf_threads: 256, 512, 768 or 1024"); opt_wf_threads = value; }
+    else if (k == "wf_wg_per_cu") { if (value < 1 || value > 8) return invalid("wf_wg_per_cu: 1..8"); opt_wf_wg_per_cu = value; }
+    else if (k == "wf_pause_lanes") { if (value < 1 || value > 64) return invalid("wf_pause_lanes: 1..64"); opt_wf_pause_lanes = value; }
     else if (k == "threads") { if (value != 64 && value != 128 && value != 256 && value != 512) return invalid("threads: 64, 128, 256 or 512"); opt_threads = value; }
     else if (k == "lds_mode") { if (value < -1 || value > 2) return invalid("lds_mode: -1..2"); opt_lds_mode = value; }
     else if (k == "steps_per_trip") { if (value < 1 || value > 64) return invalid("steps_per_trip: 1..64"); opt_steps_per_trip = value; }
@@ -304,8 +312,10 @@ rt_status rt_frame_finish(rt_scene* s, rt_stats* stats) {
     HIPCHK(hipEventSynchronize(s->ev_stop));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
-    unsigned long long rays = 0;
+    unsigned long long rays = 0, err_flag = 0;
     HIPCHK(hipMemcpy(&rays, s->d_ray_counter, sizeof(rays), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&err_flag, s->d_ray_counter + 31, sizeof(err_flag), hipMemcpyDeviceToHost));
+    if (err_flag) { s->frame_pending = false; g_detail = "render kernel hit its iteration cap (scheduler bug); frame is incomplete"; return RT_ERR_HIP; }
     s->pending_stats.ms_render = (double)ms;
     s->pending_stats.rays = rays;
     s->frame_pending = false;
@@ -382,25 +392,77 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     if (lds_mode >= 2) lds_bytes += s->sphere_bytes;
     if (lds_bytes > budget1) return invalid("requested lds_mode does not fit the CU's LDS");
 
+    // the wavefront kernel covers spheres-only scenes with inline/solid/checker textures and frames whose
+    // pixel coordinates pack into 16 bits each; everything else runs the staged kernel
+    int kernel = opt_kernel;
+    if (kernel == RT_KERNEL_WAVEFRONT && !(s->spheres_only && s->tex_level <= 1 && f->nx <= 65535 && local_rows <= 65535)) kernel = RT_KERNEL_STAGED;
+    int wf_slots = 0;
+    if (kernel == RT_KERNEL_WAVEFRONT) {
+        const int threads = opt_wf_threads;
+        const size_t cap = g_lds_per_cu / (size_t)opt_wf_wg_per_cu - 1024;
+        // prefer nodes + spheres in LDS; drop spheres to L1/L2 if that is what it takes to get >= 1.5 slots per lane
+        for (int attempt = 0; attempt < 2 && wf_slots == 0; ++attempt) {
+            size_t scene = 0;
+            if (lds_mode >= 1) scene += s->node_bytes;
+            if (lds_mode >= 2) scene += s->sphere_bytes;
+            scene = (scene + 15) & ~(size_t)15;
+            long fit = scene + 256 < cap ? (long)((cap - scene - 256) / RT_WF_BYTES_PER_SLOT) : 0;
+            fit = fit / 64 * 64;
+            if (fit > 2048) fit = 2048;
+            if (opt_wf_slots) { if (opt_wf_slots <= fit) fit = opt_wf_slots; else fit = 0; }
+            if (fit >= threads + threads / 4 || (attempt == 1 && fit >= threads)) { wf_slots = (int)fit; lds_bytes = scene + (size_t)fit * RT_WF_BYTES_PER_SLOT + 256; }
+            else if (lds_mode == 2) lds_mode = 1;
+            else break;
+        }
+        if (wf_slots == 0) { kernel = RT_KERNEL_STAGED; lds_mode = opt_lds_mode; }
+    }
+    if (kernel != opt_kernel && kernel == RT_KERNEL_STAGED && opt_kernel == RT_KERNEL_WAVEFRONT) {
+        // recompute the plain LDS plan for the fallback
+        lds_mode = opt_lds_mode;
+        if (lds_mode < 0) {
+            if (s->node_bytes + s->sphere_bytes <= budget2) lds_mode = 2;
+            else if (s->node_bytes <= budget2) lds_mode = 1;
+            else if (s->node_bytes + s->sphere_bytes <= budget1) lds_mode = 2;
+            else if (s->node_bytes <= budget1) lds_mode = 1;
+            else lds_mode = 0;
+        }
+        lds_bytes = 0;
+        if (lds_mode >= 1) lds_bytes += s->node_bytes;
+        if (lds_mode >= 2) lds_bytes += s->sphere_bytes;
+    }
+    fp.wf_slots = wf_slots;
+    fp.wf_pause_lanes = opt_wf_pause_lanes;
+    {   // generous bound: every live slot retires a ray segment (or a paused walk advances) each iteration
+        const double segs = (double)local_rows * f->nx * (double)f->ns * 51.0;
+        const double per_wg = segs / (wf_slots > 0 ? wf_slots : 1) * 4.0 + 100000.0;
+        fp.wf_max_iterations = per_wg > 4.0e9 ? 4000000000u : (uint32_t)per_wg;
+    }
+
     dim3 grid, block;
-    if (opt_kernel == RT_KERNEL_PIXEL) {
+    if (kernel == RT_KERNEL_WAVEFRONT) {
+        block = dim3(opt_wf_threads);
+        const unsigned need = (fp.work_items + (unsigned)wf_slots - 1) / (unsigned)wf_slots;
+        const unsigned want = (unsigned)(g_num_cu * opt_wf_wg_per_cu);
+        grid = dim3(want < need ? want : need);
+    } else if (kernel == RT_KERNEL_PIXEL) {
         block = dim3(256);
         grid = dim3((fp.work_items + 255u) / 256u);
     } else {
-        block = dim3(opt_threads);
+        block = dim3(kernel == RT_KERNEL_PIXEL ? 256 : opt_threads);
         int per_cu = opt_wg_per_cu;
         if (lds_bytes) { const int fit = (int)(g_lds_per_cu / (lds_bytes + 512)); if (fit < per_cu) per_cu = fit < 1 ? 1 : fit; }
         unsigned want = (unsigned)(g_num_cu * per_cu);
         const unsigned need = (fp.work_items + opt_threads - 1) / opt_threads;
         grid = dim3(want < need ? want : need);
     }
-    out.kernel_variant = opt_kernel * 1000 + lds_mode * 100 + s->tex_level * 10 + (s->spheres_only ? 1 : 0);
+    out.kernel_variant = kernel * 1000 + lds_mode * 100 + s->tex_level * 10 + (s->spheres_only ? 1 : 0);
     out.workgroups = (int)grid.x; out.threads_per_group = (int)block.x; out.lds_bytes = (int)lds_bytes;
 
     HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 256, stream));
     HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
     HIPCHK(hipEventRecord(s->ev_start, stream));
-    rt_launch_render(opt_kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, grid, block, lds_bytes, stream);
+    if (kernel == RT_KERNEL_WAVEFRONT) rt_launch_wavefront(lds_mode, s->tex_level, s->dev, fp, grid, block, lds_bytes, stream);
+    else rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, grid, block, lds_bytes, stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev_stop, stream));
     s->frame_pending = true;

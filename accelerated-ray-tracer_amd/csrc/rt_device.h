@@ -11,7 +11,7 @@
 #define RT_PARKED_MIN_WAVES 4   // waves per SIMD the parked kernel is register-limited to allow
 #endif
 
-enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_PERSISTENT = 1, RT_KERNEL_PARKED = 2, RT_KERNEL_STAGED = 3 };
+enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_PERSISTENT = 1, RT_KERNEL_PARKED = 2, RT_KERNEL_STAGED = 3, RT_KERNEL_WAVEFRONT = 4 };
 
 // device-resident scene: the rt_scene_desc arrays after upload
 struct rt_scene_dev {
@@ -46,7 +46,13 @@ struct rt_frame_params {
     int32_t leaf_threshold;               // parked kernel: parked lanes that trigger the leaf pass
     int32_t diel_threshold;               // staged kernel: dielectric hits that trigger their stage
     int32_t newpath_threshold;            // staged kernel: ended paths that trigger the new-path stage
+    int32_t wf_slots;                     // wavefront kernel: ray slots per workgroup (multiple of 64)
+    uint32_t wf_max_iterations;           // wavefront kernel: safety cap on workgroup iterations
+    int32_t wf_pause_lanes;               // wavefront kernel: a wave with fewer walking lanes re-queues them once READY is empty
 };
 
+void rt_launch_wavefront(int lds_mode, int tex_level, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block,
+                         size_t lds_bytes, hipStream_t stream);
+#define RT_WF_BYTES_PER_SLOT (31 * 4 + 5 * 2)   /* 20 float + 11 int arrays, 5 u16 lists */
 void rt_launch_render(int kernel, int lds_mode, bool spheres_only, int tex_level, bool need_uv, const rt_scene_dev& sd,
                       const rt_frame_params& fp, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream);

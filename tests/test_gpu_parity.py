@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-4
-KERNELS = [0, 1, 2, 3]   # pixel, persistent, parked, staged (the default)
+KERNELS = [0, 1, 2, 3, 4]   # pixel, persistent, parked, staged (the default), wavefront (experimental; spheres-only scenes)
 
 
 def assert_frames_equal(got, ref, what=""):
@@ -32,7 +32,7 @@ DEFAULT_KERNEL = 3
 def render(art, hs, kernel=DEFAULT_KERNEL, opts=None, **frame_kw):
     art.set_option("kernel", kernel)
     defaults = {"lds_mode": -1, "steps_per_trip": 8, "shade_threshold": 24, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512,
-                "diel_threshold": 4, "newpath_threshold": 16}
+                "diel_threshold": 4, "newpath_threshold": 16, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1}
     defaults.update(opts or {})
     for k, v in defaults.items():
         art.set_option(k, v)
@@ -116,6 +116,8 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
     variants = [(3, {}), (3, {"lds_mode": 0}), (3, {"lds_mode": 1}), (3, {"steps_per_trip": 1, "shade_threshold": 1, "diel_threshold": 1, "newpath_threshold": 1}),
                 (3, {"steps_per_trip": 11, "shade_threshold": 64, "diel_threshold": 64, "newpath_threshold": 64}), (3, {"threads": 256, "wg_per_cu": 3}),
                 (3, {"threads": 64, "wg_per_cu": 8, "shade_threshold": 40, "newpath_threshold": 3}),
+                (4, {}), (4, {"wf_threads": 1024, "lds_mode": 1}), (4, {"wf_threads": 256, "wf_slots": 384, "wf_wg_per_cu": 3, "lds_mode": 0, "wf_pause_lanes": 64}),
+                (4, {"wf_pause_lanes": 1, "steps_per_trip": 3}),
                 (1, {}), (2, {}), (2, {"lds_mode": 0}), (2, {"lds_mode": 1}), (1, {"lds_mode": 0}), (0, {"lds_mode": 0}),
                 (2, {"steps_per_trip": 1}), (2, {"steps_per_trip": 13, "leaf_threshold": 40}), (2, {"shade_threshold": 1}),
                 (2, {"shade_threshold": 64, "leaf_threshold": 64}), (2, {"threads": 256, "wg_per_cu": 3}), (2, {"threads": 64, "wg_per_cu": 8}),

@@ -13,14 +13,14 @@ ap.add_argument("--scene", default="random_scene"); ap.add_argument("--nx", type
 ap.add_argument("--ns", type=int, default=50); ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("cfgs", nargs="+")
 a = ap.parse_args()
-DEFAULTS = {"kernel": 3, "diel_threshold": 4, "newpath_threshold": 16, "lds_mode": -1, "steps_per_trip": 8, "shade_threshold": 24, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512}
+DEFAULTS = {"kernel": 3, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1, "diel_threshold": 4, "newpath_threshold": 16, "lds_mode": -1, "steps_per_trip": 8, "shade_threshold": 24, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512}
 art.init(0)
 img, iw, ih = art.default_texture()
 hs = art.HostScene(a.scene, a.nx, a.ny, img, iw, ih)
 ds = art.DeviceScene(hs)
 frame = hs.frame(nx=a.nx, ny=a.ny, ns=a.ns)
 buf = torch.zeros((a.ny, a.nx, 3), dtype=torch.float32, device="cuda")
-times = {c: [] for c in a.cfgs}; digest = {}; rays = {}
+times = {c: [] for c in a.cfgs}; digest = {}; rays = {}; variant = {}
 for rnd in range(a.rounds):
     for c in a.cfgs:
         opts = dict(DEFAULTS)
@@ -29,9 +29,9 @@ for rnd in range(a.rounds):
         for k, v in opts.items(): art.set_option(k, v)
         buf.zero_()
         _, st = ds.render(frame, out=buf.data_ptr(), blocking=True)
-        times[c].append(st.ms_render); rays[c] = st.rays
+        times[c].append(st.ms_render); rays[c] = st.rays; variant[c] = (st.kernel_variant, st.workgroups, st.threads_per_group, st.lds_bytes)
         if rnd == 0: digest[c] = hashlib.sha1(buf.cpu().numpy().tobytes()).hexdigest()[:12]
 ref = digest[a.cfgs[0]]
 for c in a.cfgs:
     t = times[c]
-    print(f"{c:60s} min {min(t):9.3f} ms  med {float(np.median(t)):9.3f} ms  {rays[c]/min(t)/1e3:9.1f} Mrays/s  frame {'same' if digest[c]==ref else 'DIFFERENT '+digest[c]}", flush=True)
+    print(f"{c:60s} min {min(t):9.3f} ms  med {float(np.median(t)):9.3f} ms  {rays[c]/min(t)/1e3:9.1f} Mrays/s  frame {'same' if digest[c]==ref else 'DIFFERENT '+digest[c]}  {variant[c]}", flush=True)
