@@ -150,9 +150,15 @@ def load_ppm(path: str):
     return buf, w.value, h.value
 
 
-def default_texture():
-    """The earth map used by the reference's `earth` and `final` scenes, if the asset is present."""
-    p = os.path.join(REPO_ROOT, "assets", "earthmap.ppm")
+SCENE_TEXTURES = {"earth": "earthmap.ppm", "final": "earthmap.ppm", "simple_light": "poolball.ppm", "original": "8ball.ppm"}
+
+
+def default_texture(scene: str = "final"):
+    """The image a reference scene loads (main.cu:816,1010,1186,1254), decoded once to assets/*.ppm; (None,0,0) otherwise."""
+    name = SCENE_TEXTURES.get(scene)
+    if name is None:
+        return None, 0, 0
+    p = os.path.join(REPO_ROOT, "assets", name)
     return load_ppm(p) if os.path.exists(p) else (None, 0, 0)
 
 

@@ -29,7 +29,7 @@ int opt_shade_threshold = 24;
 int opt_wg_per_cu = 2;
 int opt_leaf_threshold = 1;
 int opt_threads = RT_PERSISTENT_THREADS;
-int opt_diel_threshold = 4;
+int opt_diel_threshold = 2;
 int opt_newpath_threshold = 16;
 int opt_wf_slots = 0;            // 0 = as many as fit in LDS (<= 1024)
 int opt_wf_pause_lanes = 32;
@@ -149,16 +149,23 @@ rt_status validate(const rt_scene_desc* d, bool& spheres_only, int& tex_level, b
         if (t.kind == RT_TEX_CHECKER) {
             // even/odd must point at later-or-earlier non-self entries that terminate: forbid checker children
             if (t.a < 0 || t.a >= d->n_textures || t.b < 0 || t.b >= d->n_textures) return invalid("checker child out of range");
-            if (d->textures[t.a].kind == RT_TEX_CHECKER || d->textures[t.b].kind == RT_TEX_CHECKER)
-                return invalid("nested checker textures are not supported");
+            if (d->textures[t.a].kind == RT_TEX_CHECKER || d->textures[t.b].kind == RT_TEX_CHECKER ||
+                d->textures[t.a].kind == RT_TEX_UV_OFFSET || d->textures[t.b].kind == RT_TEX_UV_OFFSET)
+                return invalid("checker children must be plain textures");
         } else if (t.kind == RT_TEX_IMAGE) {
             need_uv = true; tex_level = 2;
             if (t.a >= 0) {
                 if (t.b <= 0 || t.c <= 0) return invalid("image texture with non-positive size");
                 if ((size_t)t.a + (size_t)t.b * t.c * 3 > d->image_bytes) return invalid("image texture outside the image pool");
             }
-        } else if (t.kind == RT_TEX_NOISE) {
+        } else if (t.kind == RT_TEX_NOISE || t.kind == RT_TEX_NOODLE || t.kind == RT_TEX_FELT) {
             tex_level = 2;
+            if (t.kind == RT_TEX_NOODLE && (t.a < 0 || t.a > 16)) return invalid("noodle texture octaves out of range");
+        } else if (t.kind == RT_TEX_UV_OFFSET) {
+            tex_level = 2; need_uv = true;
+            if (t.a < 0 || t.a >= d->n_textures) return invalid("uv_offset child out of range");
+            if (d->textures[t.a].kind == RT_TEX_UV_OFFSET || d->textures[t.a].kind == RT_TEX_CHECKER)
+                return invalid("uv_offset may wrap image, solid, noise, noodle or felt textures only");
         } else if (t.kind != RT_TEX_SOLID) {
             return invalid("unknown texture kind");
         }

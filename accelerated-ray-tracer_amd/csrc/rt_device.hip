@@ -349,12 +349,19 @@ DEV float clamp01(float x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
 template <int TEX>
 DEV f3 texture_value(const SceneView& sc, int tex, float u, float v, f3 p) {
     rt_texture t = sc.textures[tex];
-    while (t.kind == RT_TEX_CHECKER) {                      // texture.cuh:35-42
-        const int xi = (int)floorf(t.scale * p.x);
-        const int yi = (int)floorf(t.scale * p.y);
-        const int zi = (int)floorf(t.scale * p.z);
-        const bool is_even = ((xi + yi + zi) & 1) == 0;
-        t = sc.textures[is_even ? t.a : t.b];
+    while (t.kind == RT_TEX_CHECKER || (TEX >= 2 && t.kind == RT_TEX_UV_OFFSET)) {
+        if (TEX >= 2 && t.kind == RT_TEX_UV_OFFSET) {       // texture.cuh:156-160
+            float uu = u + t.scale; uu -= floorf(uu);
+            float vv = v + t.p[0]; vv = fminf(fmaxf(vv, 0.f), 1.f);
+            u = uu; v = vv;
+            t = sc.textures[t.a];
+        } else {                                            // texture.cuh:35-42
+            const int xi = (int)floorf(t.scale * p.x);
+            const int yi = (int)floorf(t.scale * p.y);
+            const int zi = (int)floorf(t.scale * p.z);
+            const bool is_even = ((xi + yi + zi) & 1) == 0;
+            t = sc.textures[is_even ? t.a : t.b];
+        }
     }
     if (TEX < 2 || t.kind == RT_TEX_SOLID) return ld3(t.color);
     if (t.kind == RT_TEX_IMAGE) {                           // texture.cuh:51-59
@@ -365,6 +372,23 @@ DEV f3 texture_value(const SceneView& sc, int tex, float u, float v, f3 p) {
         const uint8_t* px = sc.images + (size_t)t.a + (size_t)(j * t.b + i) * 3;
         const float inv255 = 1.f / 255.f;
         return mk3(inv255 * (float)px[0], inv255 * (float)px[1], inv255 * (float)px[2]);
+    }
+    if (t.kind == RT_TEX_NOODLE) {                          // texture.cuh:94-100
+        const f3 dir = mk3(t.p[3], t.p[4], t.p[5]);
+        const float uu = dot(p, dir);
+        const float wig = perlin_turb(t.p[7] * p, t.a);
+        const float stripes = fabsf(cr_sin(t.scale * uu + t.p[6] * wig));
+        const float q = clamp01((stripes - 0.75f) / (0.98f - 0.75f));          // smoothstep, texture.cuh:78-82
+        const float w = q * q * (3.0f - 2.0f * q);
+        return (1.f - w) * mk3(t.p[0], t.p[1], t.p[2]) + w * ld3(t.color);
+    }
+    if (t.kind == RT_TEX_FELT) {                            // texture.cuh:124-147
+        const float m = perlin_noise(t.scale * p);
+        const float phase = p.x * t.p[1] + 2.0f * perlin_turb(0.5f * p, 2);
+        const float fibers = 0.5f * (1.0f + cr_sin(phase));
+        float gain = 1.0f + t.p[0] * (m - 0.5f) + t.p[2] * (fibers - 0.5f);
+        gain = fminf(fmaxf(gain, 0.7f), 1.2f);
+        return gain * ld3(t.color);
     }
     // noise (texture.cuh:67-72)
     const float s = cr_sin(t.scale * p.z + 10.0f * perlin_turb(p, 7));

@@ -228,6 +228,13 @@ struct flattener {
             }
         } else if (auto nz = dynamic_cast<const noise_texture*>(t)) {
             r.scale = nz->scale;
+        } else if (auto nd = dynamic_cast<const noodle_texture*>(t)) {
+            r.scale = nd->k; r.p[6] = nd->A; r.p[7] = nd->f; r.a = nd->octaves;
+            put3(r.color, nd->cN); put3(r.p, nd->cG); put3(r.p + 3, nd->d);
+        } else if (auto fe = dynamic_cast<const felt_texture*>(t)) {
+            put3(r.color, fe->base_col); r.scale = fe->m_scale; r.p[0] = fe->m_amt; r.p[1] = fe->f_scale; r.p[2] = fe->f_amt;
+        } else if (auto uo = dynamic_cast<const uv_offset_texture*>(t)) {
+            r.a = texture_id(uo->base_); r.scale = uo->du; r.p[0] = uo->dv;
         } else {
             fail("texture kind not supported by the render kernels");
         }

@@ -143,6 +143,36 @@ public:
     int tex_kind() const override { return RT_TEX_NOISE; }
 };
 
+// src/texture.cuh:84-103
+class noodle_texture : public texture {
+public:
+    float k, A, f;
+    int octaves;
+    vec3 d, cN, cG;
+    noodle_texture(float stripes_k = 3.0f, float wiggle_amp = 3.0f, float wiggle_freq = 0.6f, int oct = 3,
+                   vec3 dir = vec3(0, 0, 1), vec3 noodle = vec3(0.92f, 0.85f, 0.65f), vec3 gap = vec3(0.35f, 0.20f, 0.10f))
+        : k(stripes_k), A(wiggle_amp), f(wiggle_freq), octaves(oct), d(unit_vector(dir)), cN(noodle), cG(gap) {}
+    int tex_kind() const override { return RT_TEX_NOODLE; }
+};
+// src/texture.cuh:109-148
+class felt_texture : public texture {
+public:
+    vec3 base_col;
+    float m_scale, m_amt, f_scale, f_amt;
+    felt_texture(const vec3& base = vec3(0.06f, 0.36f, 0.18f), float mottling_scale = 16.0f, float mottling_amt = 0.08f,
+                 float fiber_scale = 4.0f, float fiber_amt = 0.03f)
+        : base_col(base), m_scale(mottling_scale), m_amt(mottling_amt), f_scale(fiber_scale), f_amt(fiber_amt) {}
+    int tex_kind() const override { return RT_TEX_FELT; }
+};
+// src/texture.cuh:151-164
+class uv_offset_texture : public texture {
+public:
+    texture* base_;
+    float du, dv;
+    uv_offset_texture(texture* base, float u_offset_turns, float v_offset = 0.f) : base_(base), du(u_offset_turns), dv(v_offset) {}
+    int tex_kind() const override { return RT_TEX_UV_OFFSET; }
+};
+
 // ------------------------------------------------------------------ materials
 // src/material.cuh:46-201
 class material : public object {

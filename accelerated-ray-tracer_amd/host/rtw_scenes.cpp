@@ -264,6 +264,58 @@ void final_scene(built_scene& sc) {
     finish(sc, objs, new camera(eye, target, vec3(0, 1, 0), 40.0f, aspect_of(sc.nx, sc.ny), 0.0f, (eye - target).length(), 0.0, 1.0));
 }
 
+// ---- main.cu:360-400 + 995-1070 ----
+void simple_light(built_scene& sc) {
+    std::vector<hittable*> objs;
+    objs.push_back(new sphere(vec3(0, -1000, 0), 1000.f, new lambertian(new felt_texture(vec3(0.06f, 0.36f, 0.18f), 16.0f, 0.08f, 4.0f, 0.03f))));
+    texture* decal = new uv_offset_texture(new image_texture(image_view(sc)), 60.0f / 360.0f);
+    const vec3 centre(0, 2, 0);
+    const float radius = 2.0f;
+    objs.push_back(new sphere(centre, radius, new lambertian(decal)));
+    objs.push_back(new sphere(centre, radius + 0.02f, new dielectric(1.5f)));          // clear coat
+    objs.push_back(new sphere(vec3(0, 7, 0), 2.f, new diffuse_light(vec3(4, 4, 4))));
+    objs.push_back(new quad(vec3(3, 1, -2), vec3(2, 0, 0), vec3(0, 2, 0), new diffuse_light(vec3(4, 4, 4))));
+    const vec3 eye(26, 3, 6), target(0, 2, 0);
+    finish(sc, objs, new camera(eye, target, vec3(0, 1, 0), 20.0f, aspect_of(sc.nx, sc.ny), 0.0f, (eye - target).length(), 0.0, 1.0));
+}
+
+// ---- main.cu:564-635 + 1239-1305: the scene the reference's main() actually renders (case 10) ----
+void original_scene(built_scene& sc) {
+    std::vector<hittable*> objs;
+    material* white = new lambertian(vec3(.73f, .73f, .73f));
+    material* pink = new lambertian(vec3(0.88f, 0.50f, 0.76f));
+    material* lamp = new diffuse_light(vec3(7, 7, 7));
+    for (int ix = 0; ix < 20; ++ix) {
+        for (int iz = 0; iz < 20; ++iz) {
+            const float side = 100.0f;
+            const float x0 = -1000.0f + ix * side;
+            const float z0 = -1000.0f + iz * side;
+            const float top = 1.0f + 100.0f * ((ix * 13 + iz * 37) % 100) / 100.0f;
+            objs.push_back(make_box(vec3(x0, 0, z0), vec3(x0 + side, top, z0 + side), pink));
+        }
+    }
+    objs.push_back(new quad(vec3(123, 554, 147), vec3(300, 0, 0), vec3(0, 0, 265), lamp, true));
+    const vec3 from(400, 400, 200);
+    objs.push_back(new sphere(from, from + vec3(30, 0, 0), 50.f, new lambertian(vec3(0.0488f, 0.0148f, 0.0171f))));
+    objs.push_back(new sphere(vec3(260, 150, 45), 50.f, new dielectric(1.5f)));
+    objs.push_back(new sphere(vec3(0, 150, 145), 50.f, new metal(vec3(0.6387f, 0.3605f, 0.8826f), 1.0f)));
+    objs.push_back(new sphere(vec3(360.f, 150.f, 145.f), 70.f, new lambertian(new image_texture(image_view(sc)))));   // 8-ball
+    objs.push_back(new sphere(vec3(360, 150, 145), 70.f + 0.5f, new dielectric(1.5f)));
+    objs.push_back(new constant_medium(new sphere(vec3(0, 0, 0), 5000.f, new dielectric(1.5f)), 0.0001f, vec3(1, 1, 1)));
+    objs.push_back(new sphere(vec3(400, 200, 400), 100.f, new metal(vec3(0.23f, 0.24f, 0.85f), 0.02f)));
+    objs.push_back(new sphere(vec3(220, 280, 300), 80.f, new lambertian(new noodle_texture(0.2f))));
+    const float turn = 15.0f * 0.017453292519943295f;
+    const float ct = cosf(turn), st = sinf(turn);
+    for (int j = 0; j < 1000; ++j) {
+        const vec3 q = random_in_unit_cube(j) * 165.0f;
+        const vec3 turned(ct * q.x() + st * q.z(), q.y(), -st * q.x() + ct * q.z());
+        objs.push_back(new sphere(turned + vec3(-100, 270, 395), 10.0f, white));
+    }
+    const vec3 eye(478, 278, -600), target(278, 278, 0);
+    finish(sc, objs, new camera(eye, target, vec3(0, 1, 0), 40.0f, aspect_of(sc.nx, sc.ny), 0.0f, (eye - target).length(), 0.0, 1.0));
+    sc.background = vec3(0.043f, 0.030f, 0.094f);      // main.cu:1276
+}
+
 struct entry {
     const char* name;
     void (*build)(built_scene&);
@@ -282,6 +334,8 @@ const entry k_scenes[] = {
     {"cornell", cornell_box, 600, 600, 10000},
     {"cornell_smoke", cornell_smoke, 600, 600, 1000},
     {"final", final_scene, 800, 800, 10000},
+    {"simple_light", simple_light, 1200, 600, 10000},
+    {"original", original_scene, 800, 800, 10000},
 };
 const int k_num_scenes = (int)(sizeof(k_scenes) / sizeof(k_scenes[0]));
 

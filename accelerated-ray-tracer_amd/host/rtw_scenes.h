@@ -29,7 +29,7 @@ struct built_scene {
 };
 
 // Names: two_spheres, bouncing (alias random_scene), book1, checker, earth,
-// perlin, quads, cornell, cornell_smoke, final.  nx/ny <= 0 pick the reference
+// perlin, quads, cornell, cornell_smoke, final, simple_light, original.  nx/ny <= 0 pick the reference
 // host function's size.  `rgb` (optional, RGB8 w*h*3) feeds image textures
 // (earth, final); without it they render the reference's invalid-image colour.
 std::unique_ptr<built_scene> build_scene(const std::string& name, int nx, int ny,

@@ -128,7 +128,7 @@ def main():
         k, v = kv.split("=")
         art.set_option(k, int(v))
 
-    img, iw, ih = art.default_texture()
+    img, iw, ih = art.default_texture(args.scene)
     hs = art.HostScene(args.scene, args.nx, args.ny, img, iw, ih)
     ds = art.DeviceScene(hs)
     frame = hs.frame(nx=args.nx, ny=args.ny, ns=args.ns, tile_rows=TILE_ROWS if world > 1 else args.ny,

@@ -113,17 +113,24 @@ typedef struct rt_material {
     float pad;
 } rt_material; /* 32 B */
 
-enum { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_IMAGE = 2, RT_TEX_NOISE = 3 };
-/* texture.cuh:16-76.  checker: a/b = even/odd texture index, scale = 1/scale.
+enum { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_IMAGE = 2, RT_TEX_NOISE = 3, RT_TEX_NOODLE = 4, RT_TEX_FELT = 5, RT_TEX_UV_OFFSET = 6 };
+/* texture.cuh:16-164.
+ * checker: a/b = even/odd texture index, scale = 1/scale.
  * image: a = byte offset into `images`, b = width, c = height (RGB8).
- * noise: scale. */
+ * noise: scale.
+ * noodle (texture.cuh:84-103): scale = k, p[6] = A, p[7] = f, a = octaves, p[3..5] = unit direction,
+ *   color = noodle colour, p[0..2] = gap colour.
+ * felt (texture.cuh:109-148): color = base, scale = mottling scale, p[0] = mottling amount, p[1] = fibre scale,
+ *   p[2] = fibre amount.
+ * uv_offset (texture.cuh:151-164): a = wrapped texture, scale = du (turns), p[0] = dv. */
 typedef struct rt_texture {
     int32_t kind;
     int32_t a, b;
     float scale;
     float color[3];
     int32_t c;
-} rt_texture; /* 32 B */
+    float p[8];
+} rt_texture; /* 64 B */
 
 /* camera (camera.cuh:18-79) after init() */
 typedef struct rt_camera {

@@ -196,13 +196,16 @@ inline float perlin_turb(V3 p, int depth) {                                     
 
 // ---------------------------------------------------------------- textures
 // texture.cuh:7-76
-enum TexKind { TEX_SOLID, TEX_CHECKER, TEX_IMAGE, TEX_NOISE };
+enum TexKind { TEX_SOLID, TEX_CHECKER, TEX_IMAGE, TEX_NOISE, TEX_NOODLE, TEX_FELT, TEX_UVOFF };
 struct Tex {
     TexKind kind = TEX_SOLID;
     V3 color = {0, 0, 0};
     float inv_scale = 1.f; const Tex* even = nullptr; const Tex* odd = nullptr;   // checker
     const unsigned char* img = nullptr; int w = 0, h = 0;                           // image (bpp 3)
     float scale = 1.f;                                                              // noise
+    float k = 3.f, A = 3.f, f = 0.6f; int octaves = 3; V3 dir = {0, 0, 1}, cN = {0, 0, 0}, cG = {0, 0, 0};   // noodle
+    float m_scale = 16.f, m_amt = 0.08f, f_scale = 4.f, f_amt = 0.03f;             // felt (base colour in `color`)
+    const Tex* base = nullptr; float du = 0.f, dv = 0.f;                            // uv_offset
 };
 inline float clamp01(float x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
 V3 tex_value(const Tex* t, float u, float v, V3 p) {
@@ -223,6 +226,27 @@ V3 tex_value(const Tex* t, float u, float v, V3 p) {
         int idx = (j * t->w + i) * 3;
         const float inv255 = 1.f / 255.f;
         return v3(inv255 * (float)t->img[idx + 0], inv255 * (float)t->img[idx + 1], inv255 * (float)t->img[idx + 2]);
+    }
+    case TEX_NOODLE: {                                                              // texture.cuh:94-100
+        float uu = vdot(p, t->dir);
+        float wig = perlin_turb(vscale(t->f, p), t->octaves);
+        float stripes = fabsf(cr_sinf(t->k * uu + t->A * wig));
+        float q = clamp01((stripes - 0.75f) / (0.98f - 0.75f));                    // smoothstep, texture.cuh:78-82
+        float w = q * q * (3.0f - 2.0f * q);
+        return vadd(vscale(1.f - w, t->cG), vscale(w, t->cN));
+    }
+    case TEX_FELT: {                                                                // texture.cuh:124-147
+        float m = perlin_noise(vscale(t->m_scale, p));
+        float phase = p.x * t->f_scale + 2.0f * perlin_turb(vscale(0.5f, p), 2);
+        float fibers = 0.5f * (1.0f + cr_sinf(phase));
+        float gain = 1.0f + t->m_amt * (m - 0.5f) + t->f_amt * (fibers - 0.5f);
+        gain = fminf(fmaxf(gain, 0.7f), 1.2f);
+        return vscale(gain, t->color);
+    }
+    case TEX_UVOFF: {                                                               // texture.cuh:156-160
+        float uu = u + t->du; uu -= floorf(uu);
+        float vv = v + t->dv; vv = fminf(fmaxf(vv, 0.f), 1.f);
+        return tex_value(t->base, uu, vv, p);
     }
     case TEX_NOISE: {                                                               // texture.cuh:67-72
         float s = cr_sinf(t->scale * p.z + 10.0f * perlin_turb(p, 7));
@@ -545,6 +569,12 @@ struct Scene {
         auto t = new Tex; t->kind = TEX_CHECKER; t->inv_scale = 1.f / scale; t->even = e; t->odd = o; texs.emplace_back(t); return t;
     }
     Tex* tex_noise(float scale) { auto t = new Tex; t->kind = TEX_NOISE; t->scale = scale; texs.emplace_back(t); return t; }
+    Tex* tex_noodle(float k) { auto t = new Tex; t->kind = TEX_NOODLE; t->k = k; t->dir = vunit(v3(0, 0, 1));
+        t->cN = v3(0.92f, 0.85f, 0.65f); t->cG = v3(0.35f, 0.20f, 0.10f); texs.emplace_back(t); return t; }
+    Tex* tex_felt(V3 base, float ms, float ma, float fs, float fa) { auto t = new Tex; t->kind = TEX_FELT; t->color = base;
+        t->m_scale = ms; t->m_amt = ma; t->f_scale = fs; t->f_amt = fa; texs.emplace_back(t); return t; }
+    Tex* tex_uv_offset(Tex* base, float du, float dv) { auto t = new Tex; t->kind = TEX_UVOFF; t->base = base; t->du = du; t->dv = dv;
+        texs.emplace_back(t); return t; }
     Tex* tex_image() {
         auto t = new Tex; t->kind = TEX_IMAGE; texs.emplace_back(t); return t;   // bound to this->image later
     }
@@ -865,6 +895,95 @@ void scene_final(Scene& S, int nx, int ny) {
     S.gradient = 0; S.def_nx = 800; S.def_ny = 800; S.def_ns = 10000;
 }
 
+// main.cu:246-280 create_world_checker; host main.cu:746-800
+void scene_checker(Scene& S, int nx, int ny) {
+    Tex* chk = S.tex_checker(0.32f, S.tex_solid(v3(0.2f, 0.3f, 0.1f)), S.tex_solid(v3(0.9f, 0.9f, 0.9f)));
+    Mat* lam = S.lambertian(chk);
+    S.push(S.sphere(v3(0, -10, 0), 10.0f, lam));
+    S.push(S.sphere(v3(0, 10, 0), 10.0f, lam));
+    S.finish();
+    S.cam = make_camera(v3(13.0f, 2.0f, 3.0f), v3(0, 0, 0), v3(0, 1, 0), 20.0f, (float)nx / (float)ny, 0.0f, 10.0f, 0.0, 1.0);
+    S.gradient = 1; S.def_nx = 1200; S.def_ny = 600; S.def_ns = 500;
+}
+// main.cu:282-308 create_world_earth; host main.cu:802-880
+void scene_earth(Scene& S, int nx, int ny) {
+    S.push(S.sphere(v3(0, 0, 0), 2.0f, S.lambertian(S.tex_image())));
+    S.finish();
+    S.cam = make_camera(v3(0.0f, 0.0f, 12.0f), v3(0, 0, 0), v3(0, 1, 0), 20.0f, (float)nx / (float)ny, 0.0f, 12.0f, 0.0, 1.0);
+    S.gradient = 1; S.def_nx = 1200; S.def_ny = 600; S.def_ns = 500;
+}
+// main.cu:310-329 create_world_perlin (scale 4.0, main.cu:903); host main.cu:882-937
+void scene_perlin(Scene& S, int nx, int ny) {
+    Mat* lam = S.lambertian(S.tex_noise(4.0f));
+    S.push(S.sphere(v3(0, -1000, 0), 1000.f, lam));
+    S.push(S.sphere(v3(0, 2, 0), 2.f, lam));
+    S.finish();
+    S.cam = make_camera(v3(13, 2, 3), v3(0, 0, 0), v3(0, 1, 0), 20.0f, (float)nx / (float)ny, 0.0f, 10.0f, 0.0, 1.0);
+    S.gradient = 1; S.def_nx = 1200; S.def_ny = 600; S.def_ns = 500;
+}
+// main.cu:331-358 create_world_quads; host main.cu:939-993
+void scene_quads(Scene& S, int nx, int ny) {
+    S.push(S.quad(v3(-3, -2, 5), v3(0, 0, -4), v3(0, 4, 0), S.lambertian(v3(1.0f, 0.2f, 0.2f))));
+    S.push(S.quad(v3(-2, -2, 0), v3(4, 0, 0), v3(0, 4, 0), S.lambertian(v3(0.2f, 1.0f, 0.2f))));
+    S.push(S.quad(v3(3, -2, 1), v3(0, 0, 4), v3(0, 4, 0), S.lambertian(v3(0.2f, 0.2f, 1.0f))));
+    S.push(S.quad(v3(-2, 3, 1), v3(4, 0, 0), v3(0, 0, 4), S.lambertian(v3(1.0f, 0.5f, 0.0f))));
+    S.push(S.quad(v3(-2, -3, 5), v3(4, 0, 0), v3(0, 0, -4), S.lambertian(v3(0.2f, 0.8f, 0.8f))));
+    S.finish();
+    S.cam = make_camera(v3(0, 0, 9), v3(0, 0, 0), v3(0, 1, 0), 80.0f, (float)nx / (float)ny, 0.0f, 10.0f, 0.0, 1.0);
+    S.gradient = 1; S.def_nx = 1200; S.def_ny = 600; S.def_ns = 500;
+}
+
+// main.cu:360-400 create_world_simple_light; host main.cu:995-1070
+void scene_simple_light(Scene& S, int nx, int ny) {
+    S.push(S.sphere(v3(0, -1000, 0), 1000.f, S.lambertian(S.tex_felt(v3(0.06f, 0.36f, 0.18f), 16.0f, 0.08f, 4.0f, 0.03f))));
+    Tex* ball = S.tex_uv_offset(S.tex_image(), 60.0f / 360.0f, 0.f);
+    const V3 C = v3(0, 2, 0); const float R = 2.0f;
+    S.push(S.sphere(C, R, S.lambertian(ball)));
+    S.push(S.sphere(C, R + 0.02f, S.dielectric(1.5f)));
+    S.push(S.sphere(v3(0, 7, 0), 2.f, S.light(v3(4, 4, 4))));
+    S.push(S.quad(v3(3, 1, -2), v3(2, 0, 0), v3(0, 2, 0), S.light(v3(4, 4, 4))));
+    S.finish();
+    V3 from = v3(26, 3, 6), at = v3(0, 2, 0);
+    S.cam = make_camera(from, at, v3(0, 1, 0), 20.0f, (float)nx / (float)ny, 0.0f, vlen(vsub(from, at)), 0.0, 1.0);
+    S.gradient = 0; S.def_nx = 1200; S.def_ny = 600; S.def_ns = 10000;
+}
+
+// main.cu:564-635 create_world_original; host main.cu:1239-1305 (the scene the reference's main() renders)
+void scene_original(Scene& S, int nx, int ny) {
+    Mat* white = S.lambertian(v3(.73f, .73f, .73f));
+    Mat* ground = S.lambertian(v3(0.88f, 0.50f, 0.76f));
+    Mat* lamp = S.light(v3(7, 7, 7));
+    for (int ix = 0; ix < 20; ++ix) for (int iz = 0; iz < 20; ++iz) {
+        float w = 100.0f;
+        float x0 = -1000.0f + (float)ix * w;
+        float z0 = -1000.0f + (float)iz * w;
+        float y1 = 1.0f + 100.0f * (float)((ix * 13 + iz * 37) % 100) / 100.0f;
+        S.push(S.box(v3(x0, 0, z0), v3(x0 + w, y1, z0 + w), ground));
+    }
+    S.push(S.quad(v3(123, 554, 147), v3(300, 0, 0), v3(0, 0, 265), lamp, true));
+    V3 c1 = v3(400, 400, 200), c2 = vadd(c1, v3(30, 0, 0));
+    S.push(S.moving_sphere(c1, c2, 50.f, S.lambertian(v3(0.0488f, 0.0148f, 0.0171f))));
+    S.push(S.sphere(v3(260, 150, 45), 50.f, S.dielectric(1.5f)));
+    S.push(S.sphere(v3(0, 150, 145), 50.f, S.metal(v3(0.6387f, 0.3605f, 0.8826f), 1.0f)));
+    S.push(S.sphere(v3(360.f, 150.f, 145.f), 70.f, S.lambertian(S.tex_image())));
+    S.push(S.sphere(v3(360, 150, 145), 70.f + 0.5f, S.dielectric(1.5f)));
+    S.push(S.medium(S.sphere(v3(0, 0, 0), 5000.f, S.dielectric(1.5f)), 0.0001f, v3(1, 1, 1)));
+    S.push(S.sphere(v3(400, 200, 400), 100.f, S.metal(v3(0.23f, 0.24f, 0.85f), 0.02f)));
+    S.push(S.sphere(v3(220, 280, 300), 80.f, S.lambertian(S.tex_noodle(0.2f))));
+    for (int j = 0; j < 1000; ++j) {
+        V3 p = vscale(165.0f, cube_point(j));
+        float r = 15.0f * 0.017453292519943295f;
+        float c = cosf(r), s = sinf(r);
+        p = v3(c * p.x + s * p.z, p.y, -s * p.x + c * p.z);
+        p = vadd(p, v3(-100, 270, 395));
+        S.push(S.sphere(p, 10.0f, white));
+    }
+    S.finish();
+    V3 from = v3(478, 278, -600), at = v3(278, 278, 0);
+    S.cam = make_camera(from, at, v3(0, 1, 0), 40.0f, (float)nx / (float)ny, 0.0f, vlen(vsub(from, at)), 0.0, 1.0);
+    S.gradient = 0; S.background = v3(0.043f, 0.030f, 0.094f); S.def_nx = 800; S.def_ny = 800; S.def_ns = 10000;
+}
+
 // ---------------------------------------------------------------- render
 inline float apply_gamma(float c, float gamma) {                                    // main.cu:37-42
     if (gamma == 1.0f) return c;
@@ -942,6 +1061,12 @@ int orc_scene_create(const char* name, int nx, int ny, const unsigned char* img,
     else if (n == "cornell") scene_cornell(*S, nx, ny);
     else if (n == "cornell_smoke") scene_cornell_smoke(*S, nx, ny);
     else if (n == "final") scene_final(*S, nx, ny);
+    else if (n == "simple_light") scene_simple_light(*S, nx, ny);
+    else if (n == "checker") scene_checker(*S, nx, ny);
+    else if (n == "earth") scene_earth(*S, nx, ny);
+    else if (n == "perlin") scene_perlin(*S, nx, ny);
+    else if (n == "quads") scene_quads(*S, nx, ny);
+    else if (n == "original") scene_original(*S, nx, ny);
     else return -1;
     for (auto& t : S->texs) if (t->kind == TEX_IMAGE && !S->image.empty()) { t->img = S->image.data(); t->w = iw; t->h = ih; }
     g_scenes.push_back(std::move(S));

@@ -7,7 +7,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 CASES = [("two_spheres", 40, 20, 2), ("bouncing", 48, 32, 4), ("book1", 48, 32, 2), ("cornell", 32, 32, 4),
-         ("cornell_smoke", 32, 32, 4), ("final", 32, 32, 2)]
+         ("cornell_smoke", 32, 32, 4), ("final", 32, 32, 2), ("checker", 40, 20, 2), ("perlin", 32, 16, 2), ("quads", 40, 20, 2),
+         ("degenerate", 32, 16, 4)]
+# (scenes with image textures are covered against the live oracle in test_gpu_parity.py, with assets/*.ppm)
 out = {}
 for name, nx, ny, ns in CASES:
     fb, _ = oracle.OracleScene(name, nx, ny).render(ns)

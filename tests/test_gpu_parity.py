@@ -32,7 +32,7 @@ DEFAULT_KERNEL = 3
 def render(art, hs, kernel=DEFAULT_KERNEL, opts=None, **frame_kw):
     art.set_option("kernel", kernel)
     defaults = {"lds_mode": -1, "steps_per_trip": 8, "shade_threshold": 24, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512,
-                "diel_threshold": 4, "newpath_threshold": 16, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1}
+                "diel_threshold": 2, "newpath_threshold": 16, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1}
     defaults.update(opts or {})
     for k, v in defaults.items():
         art.set_option(k, v)
@@ -57,9 +57,10 @@ def test_golden_fixtures(gpu, kernel):
 
 @pytest.mark.parametrize("name,nx,ny,ns", [("two_spheres", 200, 100, 4), ("bouncing", 160, 96, 16), ("book1", 160, 96, 8),
                                            ("cornell", 96, 96, 16), ("cornell_smoke", 96, 96, 16), ("final", 80, 80, 8),
-                                           ("degenerate", 32, 16, 8)])
-def test_scene_matches_oracle(gpu, orc, earth, name, nx, ny, ns):
-    img, iw, ih = earth if name == "final" else (None, 0, 0)
+                                           ("degenerate", 32, 16, 8), ("checker", 96, 48, 8), ("earth", 96, 48, 8), ("perlin", 64, 32, 4),
+                                           ("quads", 96, 48, 8), ("simple_light", 96, 48, 16), ("original", 64, 64, 8)])
+def test_scene_matches_oracle(gpu, orc, name, nx, ny, ns):
+    img, iw, ih = gpu.default_texture(name)
     hs = gpu.HostScene(name, nx, ny, img, iw, ih)
     ref, cnt = orc.OracleScene(name, nx, ny, img, iw, ih).render(ns)
     fb, st = render(gpu, hs, DEFAULT_KERNEL, ns=ns)
@@ -212,3 +213,25 @@ def test_malformed_scene_is_rejected_on_the_host(gpu):
 def test_smoke_entry_point(gpu):
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_drop_in_executable_writes_the_reference_ppm(gpu, orc, tmp_path):
+    """lib/rayTracer is the drop-in for src/main.cu's main(): ASCII P3 on stdout, rows top to bottom, int(255.99*c)
+    unclamped (main.cu:715-727), progress + timing on stderr (main.cu:668-669,712)."""
+    import subprocess
+    exe = os.path.join(gpu.LIB_DIR, "rayTracer")
+    assert os.path.exists(exe)
+    for name, nx, ny, ns, dbl in [("bouncing", 40, 24, 3, True), ("cornell", 32, 32, 4, False)]:
+        r = subprocess.run([exe, "--scene", name, "--nx", str(nx), "--ny", str(ny), "--ns", str(ns)], capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()
+        err = r.stderr.decode()
+        assert f"Rendering a {nx}x{ny} image in 8x8 blocks." in err and "took " in err and " seconds." in err
+        toks = r.stdout.decode().split()
+        assert toks[:4] == ["P3", str(nx), str(ny), "255"]
+        got = np.array(toks[4:], np.int64).reshape(ny, nx, 3)
+        ref, _ = orc.OracleScene(name, nx, ny).render(ns)
+        scale = np.float64(255.99) if dbl else np.float32(255.99)
+        want = (scale * ref[::-1].astype(np.float64 if dbl else np.float32)).astype(np.int64)   # top row first, truncation, no clamp
+        assert np.array_equal(got, want), name
+    r = subprocess.run([exe, "--scene", "nope"], capture_output=True, timeout=60)
+    assert r.returncode != 0

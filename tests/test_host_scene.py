@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 SCENES = [("two_spheres", 200, 100), ("bouncing", 240, 160), ("book1", 120, 80), ("cornell", 120, 120),
-          ("cornell_smoke", 120, 120), ("final", 100, 100)]
+          ("cornell_smoke", 120, 120), ("final", 100, 100), ("checker", 120, 60), ("earth", 120, 60), ("perlin", 120, 60),
+          ("quads", 120, 60), ("simple_light", 120, 60), ("original", 80, 80), ("degenerate", 32, 16)]
 
 
 @pytest.mark.parametrize("name,nx,ny", SCENES)
@@ -56,7 +57,8 @@ def test_reference_scene_defaults(art):
     # what each reference host function passes to render<<<>>> (main.cu:656-661, 1074, 1130, 1179)
     expect = {"bouncing": (1200, 600, 10000, 0), "cornell": (600, 600, 10000, 0), "cornell_smoke": (600, 600, 1000, 0),
               "final": (800, 800, 10000, 0), "checker": (1200, 600, 500, 1), "quads": (1200, 600, 500, 1),
-              "two_spheres": (200, 100, 1, 1), "random_scene": (1200, 800, 500, 0)}
+              "two_spheres": (200, 100, 1, 1), "random_scene": (1200, 800, 500, 0), "simple_light": (1200, 600, 10000, 0),
+              "original": (800, 800, 10000, 0), "earth": (1200, 600, 500, 1), "perlin": (1200, 600, 500, 1)}
     for name, (nx, ny, ns, grad) in expect.items():
         hs = art.HostScene(name)
         assert (hs.nx, hs.ny, hs.ns, hs.use_gradient_bg) == (nx, ny, ns, grad), name

@@ -6,11 +6,11 @@ import numpy as np
 import accelerated_ray_tracer_amd as art
 import oracle
 
-cases = [("two_spheres", 200, 100, 4), ("bouncing", 96, 64, 8), ("book1", 96, 64, 8), ("cornell", 64, 64, 8),
+cases = [("two_spheres", 200, 100, 4), ("bouncing", 96, 64, 8), ("book1", 96, 64, 8), ("cornell", 64, 64, 8), ("simple_light", 64, 32, 8), ("original", 48, 48, 4), ("perlin", 48, 24, 4), ("earth", 48, 24, 4),
          ("cornell_smoke", 64, 64, 8), ("final", 64, 64, 8)]
 art.init(0)
-img, iw, ih = art.default_texture()
 for name, nx, ny, ns in cases:
+    img, iw, ih = art.default_texture(name)
     hs = art.HostScene(name, nx, ny, img, iw, ih)
     orc = oracle.OracleScene(name, nx, ny, img, iw, ih)
     ref, cnt = orc.render(ns)

@@ -13,9 +13,9 @@ ap.add_argument("--scene", default="random_scene"); ap.add_argument("--nx", type
 ap.add_argument("--ns", type=int, default=50); ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("cfgs", nargs="+")
 a = ap.parse_args()
-DEFAULTS = {"kernel": 3, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1, "diel_threshold": 4, "newpath_threshold": 16, "lds_mode": -1, "steps_per_trip": 8, "shade_threshold": 24, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512}
+DEFAULTS = {"kernel": 3, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1, "diel_threshold": 2, "newpath_threshold": 16, "lds_mode": -1, "steps_per_trip": 8, "shade_threshold": 24, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512}
 art.init(0)
-img, iw, ih = art.default_texture()
+img, iw, ih = art.default_texture(a.scene)
 hs = art.HostScene(a.scene, a.nx, a.ny, img, iw, ih)
 ds = art.DeviceScene(hs)
 frame = hs.frame(nx=a.nx, ny=a.ny, ns=a.ns)
