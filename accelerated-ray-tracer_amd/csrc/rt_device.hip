@@ -987,6 +987,11 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
             parked = -1;
             node = ~node;
         }
+        // a finished walk that hit nothing (main.cu:57-68) needs no stage: add the background and end the path now
+        if (node == ST_DONE && best.prim < 0) {
+            radiance = radiance + throughput * miss_color(fp, cur);
+            node = ST_NEWPATH;
+        }
         const unsigned long long walking = __ballot(node < n_nodes);
         const bool force = walking == 0ull;
         const int n_done = __popcll(__ballot(node == ST_DONE));
@@ -998,10 +1003,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
             DIAG_ADD(5, 1); DIAG_ADD(6, n_done);
             DIAG_ADD(11, __popcll(__ballot(node == ST_DONE && best.prim >= 0)));
             if (node == ST_DONE) {
-                if (best.prim < 0) {                                        // miss (main.cu:57-68)
-                    radiance = radiance + throughput * miss_color(fp, cur);
-                    node = ST_NEWPATH;
-                } else {
+                {
                     const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, best);
                     const rt_material m = sc.materials[rec.mat];
                     if (m.kind == RT_MAT_DIELECTRIC) {
@@ -1203,6 +1205,13 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
     unsigned int rays = 0;
     int cur = 0;
     bool first_iteration = true;
+#ifdef RT_DIAG
+    unsigned long long wf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // T, barrier, C, barrier, D, barrier, E, barrier+bookkeeping
+    unsigned long long wf_mark = __builtin_amdgcn_s_memtime();
+#define WF_STAMP(slot_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); wf_t[slot_] += now_ - wf_mark; wf_mark = now_; } while (0)
+#else
+#define WF_STAMP(slot_) do { } while (0)
+#endif
     // Every iteration retires at least one ray segment per live slot or advances a paused walk, so the frame needs
     // far fewer iterations than this cap; hitting it means a scheduling bug, reported through the error flag
     // (ray_counter[31]) instead of hanging the GPU.
@@ -1224,7 +1233,7 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
             bool finite_inv = true, exhausted = false;
             // Re-queueing is only worth it (and only safe against livelock) when plenty of rays are around and this
             // wave has advanced its rays at least one trip since it last looked.
-            const bool may_pause = n_ready >= 2 * (int)blockDim.x;
+            const bool may_pause = 2 * n_ready >= (int)blockDim.x;
             int trips = 0;
             for (;;) {
                 // -- finished walks -> DONE
@@ -1313,7 +1322,9 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
                 }
             }
         }
+        WF_STAMP(0);
         __syncthreads();
+        WF_STAMP(1);
 
         // =============================== C phase ===============================
         {
@@ -1387,7 +1398,9 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
                 { const int idx = wave_reserve(&L.ctr[C_DIEL_COUNT], dest == 3); if (dest == 3) L.diel[idx] = (uint16_t)slot; }
             }
         }
+        WF_STAMP(2);
         __syncthreads();
+        WF_STAMP(3);
 
         // =============================== D phase ===============================
         {
@@ -1429,7 +1442,9 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
                 { const int idx = wave_reserve(&L.ctr[C_NEW_COUNT], dest == 2); if (dest == 2) L.newpath[idx] = (uint16_t)slot; }
             }
         }
+        WF_STAMP(4);
         __syncthreads();
+        WF_STAMP(5);
 
         // =============================== E phase ===============================
         {
@@ -1495,6 +1510,7 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
                 { const int idx = wave_reserve(ready_count_next, alive); if (alive) ready_next[idx] = (uint16_t)slot; }
             }
         }
+        WF_STAMP(6);
         __syncthreads();
 
         // =============================== next iteration ===============================
@@ -1509,7 +1525,11 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
         }
         cur ^= 1;
         __syncthreads();
+        WF_STAMP(7);
     }
+#ifdef RT_DIAG
+    if (lane == 0) { for (int q = 0; q < 8; ++q) atomicAdd(fp.ray_counter + 1 + q, wf_t[q]); atomicAdd(fp.ray_counter + 9, 1ull); }
+#endif
     unsigned long long r64 = rays;
     for (int off2 = 32; off2 > 0; off2 >>= 1) r64 += __shfl_down(r64, off2, 64);
     if (lane == 0 && r64) atomicAdd(fp.ray_counter, r64);

@@ -58,8 +58,15 @@ def gather_rows(local, plan: "RowPlan", rank: int, world: int, dev):
     un-interleave into the reference's frame layout (row 0 = bottom).  Returns the full frame on rank 0, else None."""
     import torch
     import torch.distributed as dist
-    gathered = [torch.zeros_like(local) for _ in range(world)] if rank == 0 else None
-    dist.gather(local, gathered, dst=0)
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal mode only (RT_BENCH_BACKEND=gloo, several ranks sharing one GPU): gloo gathers host tensors
+        host = local.cpu()
+        got = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
+        dist.gather(host, got, dst=0)
+        gathered = [g.to(dev) for g in got] if rank == 0 else None
+    else:
+        gathered = [torch.zeros_like(local) for _ in range(world)] if rank == 0 else None
+        dist.gather(local, gathered, dst=0)
     if rank != 0:
         return None
     full = torch.zeros((plan.ny,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
@@ -115,13 +122,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RT_BENCH_DEVICE / RT_BENCH_BACKEND exist to rehearse the N > 1 path on a one-GPU box (all ranks on one device,
+    # gloo instead of RCCL); the driver's multi-GPU runs use neither.
+    device_index = int(os.environ.get("RT_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
-    art.init(local_rank)
+    art.init(device_index)
     if args.kernel is not None:
         art.set_option("kernel", args.kernel)
     for kv in args.opt:
@@ -166,8 +180,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    r = torch.tensor([float(rays_step)], dtype=torch.float64, device=dev)
+    red_dev = dev if (world == 1 or backend == "nccl") else torch.device("cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    r = torch.tensor([float(rays_step)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
