@@ -5,6 +5,7 @@
 // RT_ERR_NO_DEVICE / RT_ERR_HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -31,6 +32,13 @@ int opt_leaf_threshold = 1;
 int opt_threads = RT_PERSISTENT_THREADS;
 int opt_diel_threshold = 2;
 int opt_newpath_threshold = 16;
+int opt_sparse_stride = 8;      // lanes per pixel in sparse waves (64 / live lanes); 0 disables sparse waves
+int opt_heavy_factor_x10 = 20;   // a tile is "heavy" when its prepass cost is >= this/10 x the mean tile cost
+int opt_heavy_max_tiles = 0;     // 0 = as many as the sparse workgroups hold at once
+int opt_sparse_priority = 3;
+int opt_sparse_eager = 0;
+int opt_sparse_wg_percent = 35;   // at most this share of the workgroups starts in sparse mode
+int opt_lpt = 1;                 // cost prepass + longest-first tile order (staged kernel, ns >= 16)
 int opt_wf_slots = 0;            // 0 = as many as fit in LDS (<= 1024)
 int opt_wf_pause_lanes = 32;
 int opt_wf_threads = 512;
@@ -80,6 +88,10 @@ struct rt_scene {
     unsigned int* d_work_counter = nullptr;
     float* d_fb = nullptr;
     size_t d_fb_floats = 0;
+    unsigned int* d_tile_cost = nullptr;   // cost prepass: rays per 8x8 tile
+    unsigned int* d_tile_order = nullptr;  // tiles in descending cost
+    size_t tile_capacity = 0;
+    std::vector<unsigned int> h_tile_cost, h_tile_order;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool frame_pending = false;
     hipStream_t pending_stream = nullptr;
@@ -225,6 +237,13 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "leaf_threshold") { if (value < 1 || value > 64) return invalid("leaf_threshold: 1..64"); opt_leaf_threshold = value; }
     else if (k == "diel_threshold") { if (value < 1 || value > 64) return invalid("diel_threshold: 1..64"); opt_diel_threshold = value; }
     else if (k == "newpath_threshold") { if (value < 1 || value > 64) return invalid("newpath_threshold: 1..64"); opt_newpath_threshold = value; }
+    else if (k == "sparse_stride") { if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return invalid("sparse_stride: 0, 2, 4, ... 64"); opt_sparse_stride = value; }
+    else if (k == "heavy_factor_x10") { if (value < 10 || value > 1000) return invalid("heavy_factor_x10: 10..1000"); opt_heavy_factor_x10 = value; }
+    else if (k == "sparse_eager") { if (value < 0 || value > 1) return invalid("sparse_eager: 0 or 1"); opt_sparse_eager = value; }
+    else if (k == "sparse_priority") { if (value < 0 || value > 3) return invalid("sparse_priority: 0..3"); opt_sparse_priority = value; }
+    else if (k == "sparse_wg_percent") { if (value < 1 || value > 100) return invalid("sparse_wg_percent: 1..100"); opt_sparse_wg_percent = value; }
+    else if (k == "heavy_max_tiles") { if (value < 0 || value > 4096) return invalid("heavy_max_tiles: 0..4096"); opt_heavy_max_tiles = value; }
+    else if (k == "lpt") { if (value < 0 || value > 1) return invalid("lpt: 0 or 1"); opt_lpt = value; }
     else if (k == "wf_slots") { if (value < 0 || value > 4096 || (value % 64)) return invalid("wf_slots: 0 or a multiple of 64 up to 4096"); opt_wf_slots = value; }
     else if (k == "wf_threads") { if (value != 256 && value != 512 && value != 768 && value != 1024) return invalid("wf_threads: 256, 512, 768 or 1024"); opt_wf_threads = value; }
     else if (k == "wf_wg_per_cu") { if (value < 1 || value > 8) return invalid("wf_wg_per_cu: 1..8"); opt_wf_wg_per_cu = value; }
@@ -244,6 +263,8 @@ rt_status rt_scene_destroy(rt_scene* s) {
     if (s->d_ray_counter) (void)hipFree(s->d_ray_counter);
     if (s->d_work_counter) (void)hipFree(s->d_work_counter);
     if (s->d_fb) (void)hipFree(s->d_fb);
+    if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
+    if (s->d_tile_order) (void)hipFree(s->d_tile_order);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
     delete s;
@@ -378,6 +399,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     const int tiles_y = (local_rows + 7) / 8;
     if ((long long)fp.tiles_x * tiles_y * 64 >= (1ll << 31)) return invalid("frame too large");
     fp.work_items = (uint32_t)fp.tiles_x * (uint32_t)tiles_y * 64u;
+    fp.heavy_items = 0; fp.sparse_wgs = 0; fp.sparse_stride = 1; fp.sparse_priority = opt_sparse_priority; fp.sparse_eager = opt_sparse_eager;
     fp.steps_per_trip = opt_steps_per_trip;
     fp.shade_threshold = opt_shade_threshold;
     fp.leaf_threshold = opt_leaf_threshold;
@@ -446,6 +468,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     }
 
     dim3 grid, block;
+    int per_cu_resident = 1;   // workgroups of this launch that can be resident on one CU (persistent kernels)
     if (kernel == RT_KERNEL_WAVEFRONT) {
         block = dim3(opt_wf_threads);
         const unsigned need = (fp.work_items + (unsigned)wf_slots - 1) / (unsigned)wf_slots;
@@ -461,13 +484,71 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         unsigned want = (unsigned)(g_num_cu * per_cu);
         const unsigned need = (fp.work_items + opt_threads - 1) / opt_threads;
         grid = dim3(want < need ? want : need);
+        per_cu_resident = per_cu;
     }
     out.kernel_variant = kernel * 1000 + lds_mode * 100 + s->tex_level * 10 + (s->spheres_only ? 1 : 0);
     out.workgroups = (int)grid.x; out.threads_per_group = (int)block.x; out.lds_bytes = (int)lds_bytes;
 
+    HIPCHK(hipEventRecord(s->ev_start, stream));
+    // ---- cost prepass (staged kernel only): one sample per pixel, rays summed per 8x8 tile, tiles then served in
+    // descending cost.  A pixel's samples are one sequential chain and the dearest pixels trace ~10x the mean, so
+    // starting them first shortens the frame.  Pure scheduling: the main pass below renders every sample itself.
+    fp.tile_order = nullptr; fp.tile_cost = nullptr;
+    const size_t n_tiles = (size_t)fp.tiles_x * (size_t)tiles_y;
+    if (opt_lpt && kernel == RT_KERNEL_STAGED && f->ns >= 16 && n_tiles >= 64) {
+        if (s->tile_capacity < n_tiles) {
+            if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
+            if (s->d_tile_order) (void)hipFree(s->d_tile_order);
+            s->d_tile_cost = s->d_tile_order = nullptr; s->tile_capacity = 0;
+            HIPCHK(hipMalloc((void**)&s->d_tile_cost, n_tiles * sizeof(unsigned int)));
+            HIPCHK(hipMalloc((void**)&s->d_tile_order, n_tiles * sizeof(unsigned int)));
+            s->tile_capacity = n_tiles;
+        }
+        HIPCHK(hipMemsetAsync(s->d_tile_cost, 0, n_tiles * sizeof(unsigned int), stream));
+        HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 256, stream));
+        HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
+        rt_frame_params pre = fp;
+        pre.ns = 1; pre.tile_cost = s->d_tile_cost;
+        rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, pre, grid, block, lds_bytes, stream);
+        HIPCHK(hipGetLastError());
+        s->h_tile_cost.resize(n_tiles); s->h_tile_order.resize(n_tiles);
+        HIPCHK(hipMemcpyAsync(s->h_tile_cost.data(), s->d_tile_cost, n_tiles * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (size_t t = 0; t < n_tiles; ++t) s->h_tile_order[t] = (unsigned int)t;
+        const unsigned int* cost = s->h_tile_cost.data();
+        std::stable_sort(s->h_tile_order.begin(), s->h_tile_order.end(), [cost](unsigned int a, unsigned int b) { return cost[a] > cost[b]; });
+        HIPCHK(hipMemcpyAsync(s->d_tile_order, s->h_tile_order.data(), n_tiles * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
+        fp.tile_order = s->d_tile_order;
+        // heavy tiles: the leading tiles of the order whose cost is well above the mean go to sparse workgroups --
+        // as many as those workgroups can hold at once (a queue of heavy tiles behind too few sparse waves is worse
+        // than no sparse waves).  The grid grows by the sparse workgroups where the device has room.
+        if (opt_sparse_stride > 0 && block.x >= 64) {
+            double sum = 0.0;
+            for (size_t t = 0; t < n_tiles; ++t) sum += cost[t];
+            const double limit = sum / (double)n_tiles * (double)opt_heavy_factor_x10 / 10.0;
+            const unsigned pixels_per_wg = (block.x / 64u) * (64u / (unsigned)opt_sparse_stride);
+            const unsigned max_grid = (unsigned)(g_num_cu * per_cu_resident);
+            const unsigned cap_wgs = max_grid * (unsigned)opt_sparse_wg_percent / 100u;
+            size_t max_tiles = (size_t)cap_wgs * pixels_per_wg / 64u;
+            if (opt_heavy_max_tiles > 0 && max_tiles > (size_t)opt_heavy_max_tiles) max_tiles = (size_t)opt_heavy_max_tiles;
+            size_t heavy = 0;
+            while (heavy < n_tiles && heavy < max_tiles && (double)cost[s->h_tile_order[heavy]] >= limit && cost[s->h_tile_order[heavy]] > 0) ++heavy;
+            if (heavy > 0 && heavy * 4 < n_tiles) {
+                const unsigned wgs = (unsigned)((heavy * 64 + pixels_per_wg - 1) / pixels_per_wg);
+                const unsigned normal_need = (unsigned)((fp.work_items - heavy * 64 + block.x - 1) / block.x);
+                unsigned total = normal_need + wgs;
+                if (total > max_grid) total = max_grid;
+                if (total > wgs) {
+                    grid = dim3(total);
+                    fp.heavy_items = (uint32_t)(heavy * 64); fp.sparse_wgs = (int32_t)wgs; fp.sparse_stride = opt_sparse_stride;
+                    out.workgroups = (int)grid.x;
+                }
+            }
+        }
+    }
+    out.reserved = (int32_t)(fp.heavy_items / 64u);
     HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 256, stream));
     HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
-    HIPCHK(hipEventRecord(s->ev_start, stream));
     if (kernel == RT_KERNEL_WAVEFRONT) rt_launch_wavefront(lds_mode, s->tex_level, s->dev, fp, grid, block, lds_bytes, stream);
     else rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, grid, block, lds_bytes, stream);
     HIPCHK(hipGetLastError());

@@ -32,6 +32,8 @@ struct rt_frame_params {
     float* fb;                            // compact local rows, nx*3 floats each
     unsigned long long* ray_counter;      // += rays traced
     unsigned int* work_counter;           // persistent kernel's pixel queue head
+    const unsigned int* tile_order;       // optional: 8x8 tiles in descending cost (LPT order); null = natural order
+    unsigned int* tile_cost;              // optional: cost prepass output (rays per tile); the frame is not written
     uint64_t seed_base;
     int32_t nx, ny, ns;
     float gamma;
@@ -41,6 +43,11 @@ struct rt_frame_params {
     int32_t local_rows;                   // rows this call renders
     int32_t tiles_x;                      // 8x8 pixel tiles per local row band
     uint32_t work_items;                  // tiles_x * tiles_y * 64
+    uint32_t heavy_items;                 // staged kernel: leading work items (dearest tiles) served by sparse waves; 0 = none
+    int32_t sparse_wgs;                   // staged kernel: workgroups that start in sparse mode
+    int32_t sparse_eager;                 // staged kernel: sparse waves run every stage as soon as one lane needs it
+    int32_t sparse_priority;              // staged kernel: s_setprio level of sparse waves (0 = leave alone)
+    int32_t sparse_stride;                // staged kernel: in sparse mode only every sparse_stride-th lane takes a pixel
     int32_t steps_per_trip;               // persistent kernel: node visits between ballots
     int32_t shade_threshold;              // persistent kernel: waiting lanes that trigger shading
     int32_t leaf_threshold;               // parked kernel: parked lanes that trigger the leaf pass

@@ -521,7 +521,9 @@ DEV f3 miss_color(const rt_frame_params& fp, const Ray& r) {   // main.cu:59-65
 
 // pixel of work item w (8x8 tiles, row-major tiles): returns false if outside
 DEV bool work_to_pixel(const rt_frame_params& fp, uint32_t w, int& i, int& lrow) {
-    const uint32_t tile = w >> 6, within = w & 63u;
+    // tile_order (optional): tiles sorted by descending cost from the prepass, so that the most expensive pixels -- whose
+    // samples form the longest sequential chains -- start first.  Scheduling only.
+    const uint32_t tile = fp.tile_order ? fp.tile_order[w >> 6] : (w >> 6), within = w & 63u;
     const uint32_t tx = tile % (uint32_t)fp.tiles_x, ty = tile / (uint32_t)fp.tiles_x;
     i = (int)(tx * 8u + (within & 7u));
     lrow = (int)(ty * 8u + (within >> 3));
@@ -947,13 +949,28 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
     int node = ST_NEWPATH;       // every lane starts by asking for a pixel
     int32_t parked = -1;
     bool have_pixel = false, first = true, finite_inv = true;
-    unsigned int rays = 0;
+    unsigned int rays = 0, rays_at_pixel_start = 0;
+    // Sparse mode (see rt_abi.hip, "heavy tiles"): the first fp.sparse_wgs workgroups start by serving the queue of the
+    // few dearest tiles with only every fp.sparse_stride-th lane, because a lane's rays advance ~2.5x faster in a wave
+    // with few live lanes and those pixels' sequential chains bound the frame time.  When that queue is drained and the
+    // wave's own heavy pixels are finished it becomes an ordinary wave.  Wave-uniform.
+    bool sparse = (int)blockIdx.x < fp.sparse_wgs;
+    // A sparse wave's few lanes are on the frame's critical path: let it win instruction-issue arbitration against the
+    // three ordinary waves sharing its SIMD (priority outranks age, MI355X_MICROARCH.md "Two waves per SIMD").
+    if (sparse && fp.sparse_priority > 0) {
+        if (fp.sparse_priority == 1) __builtin_amdgcn_s_setprio(1);
+        else if (fp.sparse_priority == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
 
     for (;;) {
         DIAG_ADD(0, 1);
         // ---------------- stage A: node steps
         if (__ballot(!finite_inv && (unsigned)node < (unsigned)n_nodes) == 0ull) {
             for (int step = 0; step < fp.steps_per_trip; ++step) {
+                // nobody left walking (all parked or finished): end the trip now -- this is what keeps the latency of
+                // a wave's last few live lanes near one node step per step (end of frame, small multi-GPU partitions)
+                if (__ballot((unsigned)node < (unsigned)n_nodes) == 0ull) break;
                 DIAG_ADD(1, 1); DIAG_ADD(2, __popcll(__ballot((unsigned)node < (unsigned)n_nodes)));
                 if ((unsigned)node < (unsigned)n_nodes) {
                     const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
@@ -968,6 +985,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
             }
         } else {   // a lane's ray has a zero direction component: the reference's own slab form for this trip
             for (int step = 0; step < fp.steps_per_trip; ++step) {
+                if (__ballot((unsigned)node < (unsigned)n_nodes) == 0ull) break;
                 if ((unsigned)node < (unsigned)n_nodes) {
                     const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
                     const bool pass = slab_test(a, b, cur.o, inv, tmin, best.t);
@@ -996,9 +1014,16 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
         const bool force = walking == 0ull;
         const int n_done = __popcll(__ballot(node == ST_DONE));
         bool ran_stage = false;
+        // The thresholds are fractions of the lanes that still have work: a wave whose lanes are running out of pixels
+        // (end of the frame, or a small row partition on a multi-GPU run) must not wait for 24 lanes it no longer has.
+        const int live = __popcll(__ballot(node != ST_DEAD));
+        const int shade_need = 1 + ((fp.shade_threshold - 1) * live >> 6);
+        const int diel_need = 1 + ((fp.diel_threshold - 1) * live >> 6);
+        const int newpath_need = 1 + ((fp.newpath_threshold - 1) * live >> 6);
+        const bool eager = sparse && fp.sparse_eager;     // sparse waves trade their own throughput for latency
 
         // ---------------- stage C: classify + resolve + diffuse/metal/isotropic scatter
-        if (n_done > 0 && (n_done >= fp.shade_threshold || force)) {
+        if (n_done > 0 && (n_done >= shade_need || force || eager)) {
             ran_stage = true;
             DIAG_ADD(5, 1); DIAG_ADD(6, n_done);
             DIAG_ADD(11, __popcll(__ballot(node == ST_DONE && best.prim >= 0)));
@@ -1045,7 +1070,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
         // ---------------- stage D: dielectric scatter (material.cuh:119-159)
         {
             const int n_diel = __popcll(__ballot(node == ST_DIEL));
-            if (n_diel > 0 && (n_diel >= fp.diel_threshold || force)) {
+            if (n_diel > 0 && (n_diel >= diel_need || force || eager)) {
                 ran_stage = true;
                 DIAG_ADD(7, 1); DIAG_ADD(8, n_diel);
                 if (node == ST_DIEL) {
@@ -1060,21 +1085,36 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
         // ---------------- stage E: path end -> next sample / next pixel -> camera ray (main.cu:119-132)
         {
             const int n_new = __popcll(__ballot(node == ST_NEWPATH));
-            if (n_new > 0 && (n_new >= fp.newpath_threshold || force)) {
+            if (n_new > 0 && (n_new >= newpath_need || force || eager)) {
                 ran_stage = true;
                 DIAG_ADD(9, 1); DIAG_ADD(10, n_new);
                 if (node == ST_NEWPATH) {
                     if (!first) { col = col + radiance; ++sample; }
                     first = false;
                     bool alive = true;
-                    if (have_pixel && sample >= fp.ns) { store_pixel(fp, px_i, px_lrow, col); have_pixel = false; }
+                    if (have_pixel && sample >= fp.ns) {
+                        if (fp.tile_cost) {   // cost prepass: rays this pixel traced, summed per 8x8 tile; no pixel is written
+                            atomicAdd(&fp.tile_cost[(px_lrow >> 3) * fp.tiles_x + (px_i >> 3)], rays - rays_at_pixel_start);
+                        } else {
+                            store_pixel(fp, px_i, px_lrow, col);
+                        }
+                        have_pixel = false;
+                    }
                     while (!have_pixel && alive) {
-                        const uint32_t w = atomicAdd(fp.work_counter, 1u);
-                        if (w >= fp.work_items) { alive = false; break; }
+                        uint32_t w;
+                        if (sparse) {
+                            if (((threadIdx.x & 63) % (unsigned)fp.sparse_stride) != 0u) { alive = false; break; }
+                            w = atomicAdd(fp.work_counter + 1, 1u);                 // heavy queue: items [0, heavy_items)
+                            if (w >= fp.heavy_items) { alive = false; break; }
+                        } else {
+                            w = fp.heavy_items + atomicAdd(fp.work_counter, 1u);     // everything after the heavy tiles
+                            if (w >= fp.work_items) { alive = false; break; }
+                        }
                         if (work_to_pixel(fp, w, px_i, px_lrow)) {
                             px_j = local_to_global_row(fp, px_lrow);
                             rt_xorwow_seed(g, fp.seed_base + (uint64_t)(px_j * fp.nx + px_i));
                             col = mk3(0, 0, 0); sample = 0; have_pixel = true;
+                            rays_at_pixel_start = rays;
                         }
                     }
                     if (alive) {
@@ -1100,7 +1140,11 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                 ++rays;
             }
         } else if (force) {
-            break;   // nothing walking, nothing waiting: every lane is ST_DEAD
+            // nothing walking, nothing waiting: every lane is ST_DEAD
+            if (!sparse) break;
+            sparse = false;                         // heavy queue drained and our heavy pixels done: become an ordinary wave
+            __builtin_amdgcn_s_setprio(0);
+            node = ST_NEWPATH; first = true; have_pixel = false;
         }
     }
     unsigned long long r64 = rays;

@@ -1114,6 +1114,21 @@ void orc_render(int h, float* fb, int nx, int ny, int ns, float gamma, const flo
     }
 }
 
+// Rays traced (world->hit calls) by each pixel of row j: the per-pixel cost that bounds strong scaling.
+void orc_row_pixel_rays(int h, int nx, int ny, int ns, const float* bg, int gradient, unsigned long long seed_base, int j,
+                        unsigned long long* out_nx) {
+    const Scene& S = *g_scenes[h];
+    V3 b = v3(bg[0], bg[1], bg[2]);
+    Counters c;
+    g_cnt = &c;
+    for (int i = 0; i < nx; ++i) {
+        const unsigned long long before = c.rays;
+        (void)render_pixel(S, i, j, nx, ny, ns, 1.0f, b, gradient, seed_base);
+        out_nx[i] = c.rays - before;
+    }
+    g_cnt = nullptr;
+}
+
 // XORWOW known-answer helper: state after init (v0..v4,d) and the first n uniforms / raw words.
 void orc_xorwow(unsigned long long seed, int n, unsigned int* state6, float* uniforms, unsigned int* raw) {
     Rng g; rng_seed(g, seed);

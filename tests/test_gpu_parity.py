@@ -32,7 +32,9 @@ DEFAULT_KERNEL = 3
 def render(art, hs, kernel=DEFAULT_KERNEL, opts=None, **frame_kw):
     art.set_option("kernel", kernel)
     defaults = {"lds_mode": -1, "steps_per_trip": 8, "shade_threshold": 24, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512,
-                "diel_threshold": 2, "newpath_threshold": 16, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1}
+                "diel_threshold": 2, "newpath_threshold": 16, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1,
+                "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 20, "heavy_max_tiles": 0, "sparse_wg_percent": 35, "sparse_priority": 3,
+                "sparse_eager": 0}
     defaults.update(opts or {})
     for k, v in defaults.items():
         art.set_option(k, v)
@@ -114,7 +116,9 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
     """Everything the scheduler does is re-ordering: LDS residency, trip length, thresholds, workgroup shape."""
     hs = gpu.HostScene("bouncing", 128, 80)
     base, st0 = render(gpu, hs, 0, ns=6)
-    variants = [(3, {}), (3, {"lds_mode": 0}), (3, {"lds_mode": 1}), (3, {"steps_per_trip": 1, "shade_threshold": 1, "diel_threshold": 1, "newpath_threshold": 1}),
+    variants = [(3, {}), (3, {"lpt": 0}), (3, {"sparse_stride": 0}), (3, {"sparse_stride": 64, "heavy_factor_x10": 10, "sparse_wg_percent": 100}),
+                (3, {"sparse_stride": 2, "heavy_factor_x10": 12, "sparse_priority": 0, "sparse_eager": 1}), (3, {"heavy_max_tiles": 3, "sparse_stride": 16}),
+                (3, {"lds_mode": 0}), (3, {"lds_mode": 1}), (3, {"steps_per_trip": 1, "shade_threshold": 1, "diel_threshold": 1, "newpath_threshold": 1}),
                 (3, {"steps_per_trip": 11, "shade_threshold": 64, "diel_threshold": 64, "newpath_threshold": 64}), (3, {"threads": 256, "wg_per_cu": 3}),
                 (3, {"threads": 64, "wg_per_cu": 8, "shade_threshold": 40, "newpath_threshold": 3}),
                 (4, {}), (4, {"wf_threads": 1024, "lds_mode": 1}), (4, {"wf_threads": 256, "wf_slots": 384, "wf_wg_per_cu": 3, "lds_mode": 0, "wf_pause_lanes": 64}),
