@@ -25,15 +25,18 @@ std::string g_detail;
 // tuning knobs (rt_set_option)
 int opt_kernel = RT_KERNEL_STAGED;
 int opt_lds_mode = -1;          // -1 = choose from the scene size
-int opt_steps_per_trip = 8;
-int opt_shade_threshold = 24;
+int opt_steps_per_trip = 12;
+int opt_shade_threshold = 32;
 int opt_wg_per_cu = 2;
 int opt_leaf_threshold = 1;
 int opt_threads = RT_PERSISTENT_THREADS;
 int opt_diel_threshold = 2;
-int opt_newpath_threshold = 16;
+int opt_newpath_threshold = 24;
 int opt_sparse_stride = 8;      // lanes per pixel in sparse waves (64 / live lanes); 0 disables sparse waves
-int opt_heavy_factor_x10 = 20;   // a tile is "heavy" when its prepass cost is >= this/10 x the mean tile cost
+int opt_split_samples = 32;      // samples per pixel rendered before pixels are ranked by measured cost
+int opt_tier1_factor_x10 = 70;   // tier 1 = heavy pixels costing >= this/10 x the mean
+int opt_tier1_pixels = 256;      // heavy pixels served with one live lane per wave
+int opt_heavy_factor_x10 = 40;   // a pixel is "heavy" when its prepass ray count is >= this/10 x the mean
 int opt_heavy_max_tiles = 0;     // 0 = as many as the sparse workgroups hold at once
 int opt_sparse_priority = 3;
 int opt_sparse_eager = 0;
@@ -90,8 +93,12 @@ struct rt_scene {
     size_t d_fb_floats = 0;
     unsigned int* d_tile_cost = nullptr;   // cost prepass: rays per 8x8 tile
     unsigned int* d_tile_order = nullptr;  // tiles in descending cost
-    size_t tile_capacity = 0;
-    std::vector<unsigned int> h_tile_cost, h_tile_order;
+    rt_pixel_state* d_state = nullptr;     // split frames: pixels parked between the two parts
+    unsigned long long* d_heavy_list = nullptr;   // (cost << 32 | pixel), unsorted, from rt_collect_heavy_kernel
+    unsigned int* d_heavy_pixels = nullptr;       // heavy pixels, dearest first
+    size_t tile_capacity = 0, pixel_capacity = 0;
+    std::vector<unsigned int> h_tile_cost, h_tile_order, h_heavy_pixels;
+    std::vector<unsigned long long> h_heavy;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool frame_pending = false;
     hipStream_t pending_stream = nullptr;
@@ -239,6 +246,9 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "newpath_threshold") { if (value < 1 || value > 64) return invalid("newpath_threshold: 1..64"); opt_newpath_threshold = value; }
     else if (k == "sparse_stride") { if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return invalid("sparse_stride: 0, 2, 4, ... 64"); opt_sparse_stride = value; }
     else if (k == "heavy_factor_x10") { if (value < 10 || value > 1000) return invalid("heavy_factor_x10: 10..1000"); opt_heavy_factor_x10 = value; }
+    else if (k == "split_samples") { if (value < 1 || value > 4096) return invalid("split_samples: 1..4096"); opt_split_samples = value; }
+    else if (k == "tier1_factor_x10") { if (value < 10 || value > 10000) return invalid("tier1_factor_x10: 10..10000"); opt_tier1_factor_x10 = value; }
+    else if (k == "tier1_pixels") { if (value < 0 || value > 8192) return invalid("tier1_pixels: 0..8192"); opt_tier1_pixels = value; }
     else if (k == "sparse_eager") { if (value < 0 || value > 1) return invalid("sparse_eager: 0 or 1"); opt_sparse_eager = value; }
     else if (k == "sparse_priority") { if (value < 0 || value > 3) return invalid("sparse_priority: 0..3"); opt_sparse_priority = value; }
     else if (k == "sparse_wg_percent") { if (value < 1 || value > 100) return invalid("sparse_wg_percent: 1..100"); opt_sparse_wg_percent = value; }
@@ -265,6 +275,9 @@ rt_status rt_scene_destroy(rt_scene* s) {
     if (s->d_fb) (void)hipFree(s->d_fb);
     if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
     if (s->d_tile_order) (void)hipFree(s->d_tile_order);
+    if (s->d_state) (void)hipFree(s->d_state);
+    if (s->d_heavy_list) (void)hipFree(s->d_heavy_list);
+    if (s->d_heavy_pixels) (void)hipFree(s->d_heavy_pixels);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
     delete s;
@@ -490,65 +503,111 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     out.workgroups = (int)grid.x; out.threads_per_group = (int)block.x; out.lds_bytes = (int)lds_bytes;
 
     HIPCHK(hipEventRecord(s->ev_start, stream));
-    // ---- cost prepass (staged kernel only): one sample per pixel, rays summed per 8x8 tile, tiles then served in
-    // descending cost.  A pixel's samples are one sequential chain and the dearest pixels trace ~10x the mean, so
-    // starting them first shortens the frame.  Pure scheduling: the main pass below renders every sample itself.
-    fp.tile_order = nullptr; fp.tile_cost = nullptr;
+    // ---- cost-aware schedule (staged kernel): the frame is split at a sample boundary.
+    // A pixel's samples are one sequential chain (one XORWOW stream) and the dearest pixels of a frame trace ~10x the
+    // mean number of rays, so the frame time is bounded by a few pixels' chains, not by throughput
+    // (tools/critical_chain.py: the worst 8 rows alone take as long as the whole frame).  Part 1 renders samples
+    // [0, S0) of every pixel and parks each pixel (XORWOW state, colour sum, rays traced) -- at a sample boundary no path
+    // is in flight, so that is the whole state.  With those measured costs part 2 renders samples [S0, ns):
+    //   * 8x8 tiles are served in descending cost (longest first);
+    //   * pixels far above the mean go to a short list, dearest first, served by "sparse" workgroups at raised
+    //     priority: tier 1 (the very dearest) one live lane per wave, tier 2 a few -- a lane's rays advance about
+    //     twice as fast in a wave with few live lanes; ordinary waves skip listed pixels.
+    // Scheduling only: every sample of every pixel is rendered exactly once, in its pixel's stream order; frames are
+    // bit-identical with and without it (tests sweep the knobs).
+    fp.tile_order = nullptr; fp.tile_cost = nullptr; fp.state_out = nullptr; fp.state_in = nullptr; fp.heavy_pixels = nullptr;
+    fp.sample_begin = 0; fp.sample_end = f->ns;
+    fp.heavy_threshold = 0xFFFFFFFFu; fp.tier1_items = 0; fp.tier1_wgs = 0; fp.tier1_stride = 64;
     const size_t n_tiles = (size_t)fp.tiles_x * (size_t)tiles_y;
-    if (opt_lpt && kernel == RT_KERNEL_STAGED && f->ns >= 16 && n_tiles >= 64) {
-        if (s->tile_capacity < n_tiles) {
-            if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
-            if (s->d_tile_order) (void)hipFree(s->d_tile_order);
-            s->d_tile_cost = s->d_tile_order = nullptr; s->tile_capacity = 0;
+    const size_t n_pixels = (size_t)local_rows * (size_t)f->nx;
+    enum { RT_HEAVY_CAP = 32768 };
+    bool split = false;
+    HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 256, stream));
+    if (opt_lpt && kernel == RT_KERNEL_STAGED && f->ns >= 2 * opt_split_samples && n_tiles >= 64 && n_pixels < (1ull << 31)) {
+        if (s->tile_capacity < n_tiles || s->pixel_capacity < n_pixels) {
+            for (void* p : {(void*)s->d_tile_cost, (void*)s->d_tile_order, (void*)s->d_state, (void*)s->d_heavy_list, (void*)s->d_heavy_pixels})
+                if (p) (void)hipFree(p);
+            s->d_tile_cost = s->d_tile_order = s->d_heavy_pixels = nullptr; s->d_state = nullptr; s->d_heavy_list = nullptr;
+            s->tile_capacity = s->pixel_capacity = 0;
             HIPCHK(hipMalloc((void**)&s->d_tile_cost, n_tiles * sizeof(unsigned int)));
             HIPCHK(hipMalloc((void**)&s->d_tile_order, n_tiles * sizeof(unsigned int)));
-            s->tile_capacity = n_tiles;
+            HIPCHK(hipMalloc((void**)&s->d_state, n_pixels * sizeof(rt_pixel_state)));
+            HIPCHK(hipMalloc((void**)&s->d_heavy_list, (size_t)RT_HEAVY_CAP * sizeof(unsigned long long)));
+            HIPCHK(hipMalloc((void**)&s->d_heavy_pixels, (size_t)RT_HEAVY_CAP * sizeof(unsigned int)));
+            s->tile_capacity = n_tiles; s->pixel_capacity = n_pixels;
         }
+        // ---- part 1: samples [0, S0)
         HIPCHK(hipMemsetAsync(s->d_tile_cost, 0, n_tiles * sizeof(unsigned int), stream));
-        HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 256, stream));
         HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
-        rt_frame_params pre = fp;
-        pre.ns = 1; pre.tile_cost = s->d_tile_cost;
-        rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, pre, grid, block, lds_bytes, stream);
+        rt_frame_params p1 = fp;
+        p1.sample_end = opt_split_samples; p1.state_out = s->d_state; p1.tile_cost = s->d_tile_cost;
+        rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, p1, grid, block, lds_bytes, stream);
         HIPCHK(hipGetLastError());
         s->h_tile_cost.resize(n_tiles); s->h_tile_order.resize(n_tiles);
+        unsigned long long rays1 = 0;
         HIPCHK(hipMemcpyAsync(s->h_tile_cost.data(), s->d_tile_cost, n_tiles * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(&rays1, s->d_ray_counter, sizeof(rays1), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        split = true;
+        fp.state_in = s->d_state; fp.sample_begin = opt_split_samples;
+        // ---- tiles, dearest first
         for (size_t t = 0; t < n_tiles; ++t) s->h_tile_order[t] = (unsigned int)t;
         const unsigned int* cost = s->h_tile_cost.data();
         std::stable_sort(s->h_tile_order.begin(), s->h_tile_order.end(), [cost](unsigned int a, unsigned int b) { return cost[a] > cost[b]; });
         HIPCHK(hipMemcpyAsync(s->d_tile_order, s->h_tile_order.data(), n_tiles * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
         fp.tile_order = s->d_tile_order;
-        // heavy tiles: the leading tiles of the order whose cost is well above the mean go to sparse workgroups --
-        // as many as those workgroups can hold at once (a queue of heavy tiles behind too few sparse waves is worse
-        // than no sparse waves).  The grid grows by the sparse workgroups where the device has room.
+        // ---- heavy pixels
         if (opt_sparse_stride > 0 && block.x >= 64) {
-            double sum = 0.0;
-            for (size_t t = 0; t < n_tiles; ++t) sum += cost[t];
-            const double limit = sum / (double)n_tiles * (double)opt_heavy_factor_x10 / 10.0;
-            const unsigned pixels_per_wg = (block.x / 64u) * (64u / (unsigned)opt_sparse_stride);
-            const unsigned max_grid = (unsigned)(g_num_cu * per_cu_resident);
-            const unsigned cap_wgs = max_grid * (unsigned)opt_sparse_wg_percent / 100u;
-            size_t max_tiles = (size_t)cap_wgs * pixels_per_wg / 64u;
-            if (opt_heavy_max_tiles > 0 && max_tiles > (size_t)opt_heavy_max_tiles) max_tiles = (size_t)opt_heavy_max_tiles;
-            size_t heavy = 0;
-            while (heavy < n_tiles && heavy < max_tiles && (double)cost[s->h_tile_order[heavy]] >= limit && cost[s->h_tile_order[heavy]] > 0) ++heavy;
-            if (heavy > 0 && heavy * 4 < n_tiles) {
-                const unsigned wgs = (unsigned)((heavy * 64 + pixels_per_wg - 1) / pixels_per_wg);
-                const unsigned normal_need = (unsigned)((fp.work_items - heavy * 64 + block.x - 1) / block.x);
-                unsigned total = normal_need + wgs;
+            const double mean = (double)rays1 / (double)n_pixels;                    // rays per pixel in part 1
+            const unsigned int threshold = (unsigned int)(mean * (double)opt_heavy_factor_x10 / 10.0 + 0.999);
+            const unsigned int threshold1 = (unsigned int)(mean * (double)opt_tier1_factor_x10 / 10.0 + 0.999);
+            unsigned int* d_count = s->d_work_counter + 8;
+            HIPCHK(hipMemsetAsync(d_count, 0, sizeof(unsigned int), stream));
+            rt_launch_collect_heavy(s->d_state, (unsigned int)n_pixels, threshold, s->d_heavy_list, RT_HEAVY_CAP, d_count, stream);
+            HIPCHK(hipGetLastError());
+            unsigned int count = 0;
+            HIPCHK(hipMemcpyAsync(&count, d_count, sizeof(count), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            if (count > 0 && count <= RT_HEAVY_CAP && (size_t)count * 8 < n_pixels) {
+                s->h_heavy.resize(count);
+                HIPCHK(hipMemcpyAsync(s->h_heavy.data(), s->d_heavy_list, (size_t)count * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                std::sort(s->h_heavy.begin(), s->h_heavy.end(), [](unsigned long long a, unsigned long long b) { return a > b; });
+                s->h_heavy_pixels.resize(count);
+                unsigned tier1_items = 0;
+                for (unsigned int q = 0; q < count; ++q) {
+                    s->h_heavy_pixels[q] = (unsigned int)(s->h_heavy[q] & 0xFFFFFFFFull);
+                    if ((unsigned int)(s->h_heavy[q] >> 32) >= threshold1) tier1_items = q + 1;
+                }
+                HIPCHK(hipMemcpyAsync(s->d_heavy_pixels, s->h_heavy_pixels.data(), (size_t)count * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
+                // workgroups: tier 1 = one live lane per wave, tier 2 = 64 / sparse_stride live lanes per wave
+                const unsigned waves_per_wg = block.x / 64u;
+                const unsigned max_grid = (unsigned)(g_num_cu * per_cu_resident);
+                const unsigned cap_wgs = max_grid * (unsigned)opt_sparse_wg_percent / 100u;
+                if (tier1_items > (unsigned)opt_tier1_pixels) tier1_items = (unsigned)opt_tier1_pixels;
+                unsigned tier1_wgs = (tier1_items + waves_per_wg - 1) / waves_per_wg;
+                if (tier1_wgs > cap_wgs / 2) { tier1_wgs = cap_wgs / 2; tier1_items = tier1_wgs * waves_per_wg; if (tier1_items > count) tier1_items = count; }
+                const unsigned tier2_items = count - tier1_items;
+                const unsigned per_wg2 = waves_per_wg * (64u / (unsigned)opt_sparse_stride);
+                unsigned tier2_wgs = (tier2_items + per_wg2 - 1) / per_wg2;
+                if (tier1_wgs + tier2_wgs > cap_wgs) tier2_wgs = cap_wgs - tier1_wgs;     // the rest of tier 2 queues behind them
+                const unsigned sparse_wgs = tier1_wgs + tier2_wgs;
+                const unsigned normal_need = (unsigned)((fp.work_items + block.x - 1) / block.x);
+                unsigned total = normal_need + sparse_wgs;
                 if (total > max_grid) total = max_grid;
-                if (total > wgs) {
+                if (sparse_wgs > 0 && total > sparse_wgs) {
                     grid = dim3(total);
-                    fp.heavy_items = (uint32_t)(heavy * 64); fp.sparse_wgs = (int32_t)wgs; fp.sparse_stride = opt_sparse_stride;
+                    fp.heavy_pixels = s->d_heavy_pixels; fp.heavy_threshold = threshold;
+                    fp.heavy_items = count; fp.tier1_items = tier1_items; fp.tier1_wgs = (int32_t)tier1_wgs; fp.tier1_stride = 64;
+                    fp.sparse_wgs = (int32_t)sparse_wgs; fp.sparse_stride = opt_sparse_stride;
                     out.workgroups = (int)grid.x;
                 }
             }
         }
     }
-    out.reserved = (int32_t)(fp.heavy_items / 64u);
-    HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 256, stream));
-    HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
+    (void)split;
+    out.reserved = (int32_t)fp.heavy_items;
+    HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));   // the ray counter keeps part 1's rays
     if (kernel == RT_KERNEL_WAVEFRONT) rt_launch_wavefront(lds_mode, s->tex_level, s->dev, fp, grid, block, lds_bytes, stream);
     else rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, grid, block, lds_bytes, stream);
     HIPCHK(hipGetLastError());

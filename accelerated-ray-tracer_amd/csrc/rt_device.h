@@ -13,6 +13,13 @@
 
 enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_PERSISTENT = 1, RT_KERNEL_PARKED = 2, RT_KERNEL_STAGED = 3, RT_KERNEL_WAVEFRONT = 4 };
 
+// A pixel parked at a sample boundary (split frames): XORWOW state, colour sum, rays traced so far.
+struct rt_pixel_state {
+    uint32_t rng[6];
+    float col[3];
+    uint32_t cost;
+};
+
 // device-resident scene: the rt_scene_desc arrays after upload
 struct rt_scene_dev {
     const rt_node* nodes;
@@ -33,7 +40,14 @@ struct rt_frame_params {
     unsigned long long* ray_counter;      // += rays traced
     unsigned int* work_counter;           // persistent kernel's pixel queue head
     const unsigned int* tile_order;       // optional: 8x8 tiles in descending cost (LPT order); null = natural order
-    unsigned int* tile_cost;              // optional: cost prepass output (rays per tile); the frame is not written
+    unsigned int* tile_cost;              // first part of a split frame: rays per 8x8 tile
+    rt_pixel_state* state_out;            // first part of a split frame: where pixels are parked (the frame is not written)
+    const rt_pixel_state* state_in;       // second part: the parked pixels (null = pixels start from their seed)
+    int32_t sample_begin, sample_end;     // samples [sample_begin, sample_end) are rendered by this launch; ns is the frame's total
+    const unsigned int* heavy_pixels;     // second part: local pixel ids (lrow * nx + i) of the heavy pixels, dearest first
+    uint32_t heavy_threshold;             // pixels whose parked cost is >= this are in heavy_pixels
+    uint32_t tier1_items;                 // leading heavy_pixels entries served by tier-1 sparse workgroups
+    int32_t tier1_wgs, tier1_stride;      // tier 1: the first tier1_wgs workgroups, one pixel per tier1_stride lanes
     uint64_t seed_base;
     int32_t nx, ny, ns;
     float gamma;
@@ -43,7 +57,7 @@ struct rt_frame_params {
     int32_t local_rows;                   // rows this call renders
     int32_t tiles_x;                      // 8x8 pixel tiles per local row band
     uint32_t work_items;                  // tiles_x * tiles_y * 64
-    uint32_t heavy_items;                 // staged kernel: leading work items (dearest tiles) served by sparse waves; 0 = none
+    uint32_t heavy_items;                 // staged kernel: entries of heavy_pixels (served by sparse workgroups); 0 = none
     int32_t sparse_wgs;                   // staged kernel: workgroups that start in sparse mode
     int32_t sparse_eager;                 // staged kernel: sparse waves run every stage as soon as one lane needs it
     int32_t sparse_priority;              // staged kernel: s_setprio level of sparse waves (0 = leave alone)
@@ -58,6 +72,8 @@ struct rt_frame_params {
     int32_t wf_pause_lanes;               // wavefront kernel: a wave with fewer walking lanes re-queues them once READY is empty
 };
 
+void rt_launch_collect_heavy(const rt_pixel_state* state, unsigned int n_pixels, unsigned int threshold, unsigned long long* list,
+                             unsigned int capacity, unsigned int* count, hipStream_t st);
 void rt_launch_wavefront(int lds_mode, int tex_level, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block,
                          size_t lds_bytes, hipStream_t stream);
 #define RT_WF_BYTES_PER_SLOT (31 * 4 + 5 * 2)   /* 20 float + 11 int arrays, 5 u16 lists */

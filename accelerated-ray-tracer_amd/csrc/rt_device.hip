@@ -590,6 +590,50 @@ DEV bool trace(const SceneView& sc, const Ray& r, HitInfo& best) {
     return best.prim >= 0;
 }
 
+// One ray, the whole wave: the 64 lanes test 64 consecutive nodes of the depth-first array at once, then the walk the
+// reference would take through them (box hit -> next index or leaf test, box miss -> skip link) is replayed with scalar
+// bit tests on the ballot, v_readlane for the skip links.  Used by tier-1 waves, which hold a single pixel whose
+// sequential chain bounds the frame time: a lone lane's traversal is LDS-latency bound (one dependent node read per
+// step); here one pair of wide reads serves several steps.  Every box is still compared with the closest hit that the
+// reference would have at that visit: the batch is abandoned as soon as a leaf test changes it.  All arguments are
+// wave-uniform (every lane carries the same ray); the result is identical in all lanes.
+template <bool SPHERES_ONLY>
+DEV bool trace_wide(const SceneView& sc, const Ray& r, HitInfo& best) {
+    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const float tmin = 0.001f;
+    best.t = FLT_MAX; best.prim = -1; best.inst = -1;
+    const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
+    const int n = sc.n_nodes;
+    const int lane = (int)(threadIdx.x & 63u);
+    int i = 0;
+    while (i < n) {
+        const int idx = i + lane;
+        const bool valid = idx < n;
+        const float4 a = nodes4[2 * (valid ? idx : 0)], b = nodes4[2 * (valid ? idx : 0) + 1];
+        const bool pass = valid && slab_test(a, b, r.o, inv, tmin, best.t);
+        const int my_skip = __float_as_int(a.w), my_prim = __float_as_int(b.w);
+        const unsigned long long pass_mask = __ballot(pass);
+        const unsigned long long leaf_mask = __ballot(valid && my_prim >= 0);
+        const int end = (i + 64 < n) ? i + 64 : n;
+        int j = i;
+        while (j < end) {
+            const int bit = j - i;
+            if (!((pass_mask >> bit) & 1ull)) { j = __builtin_amdgcn_readlane(my_skip, bit); continue; }
+            if ((leaf_mask >> bit) & 1ull) {
+                const float before = best.t;
+                const int32_t before_prim = best.prim;
+                leaf_test<SPHERES_ONLY>(sc, __builtin_amdgcn_readlane(my_prim, bit), r, tmin, best);
+                j = __builtin_amdgcn_readlane(my_skip, bit);
+                if (best.t != before || best.prim != before_prim) break;   // later boxes must see the new limit
+            } else {
+                j = j + 1;
+            }
+        }
+        i = j;
+    }
+    return best.prim >= 0;
+}
+
 }  // namespace
 
 // =============================================================================
@@ -955,6 +999,50 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
     // with few live lanes and those pixels' sequential chains bound the frame time.  When that queue is drained and the
     // wave's own heavy pixels are finished it becomes an ordinary wave.  Wave-uniform.
     bool sparse = (int)blockIdx.x < fp.sparse_wgs;
+    // Tier-1 waves hold ONE pixel each -- the dearest pixels of the frame, whose sequential chains bound the frame time.
+    // With a single live lane the state machine below is pure overhead, so they run the reference's plain loop nest
+    // (as kernel A does) on pixels parked by part 1, one after another, and only then join the ordinary waves.
+    if (sparse && (int)blockIdx.x < fp.tier1_wgs && fp.state_in) {
+        __builtin_amdgcn_s_setprio(3);
+        // every lane of the wave carries the same pixel and computes the same values; only trace_wide() differs per lane
+        for (;;) {
+            uint32_t idx = 0;
+            if ((threadIdx.x & 63) == 0) idx = atomicAdd(fp.work_counter + 2, 1u);
+            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+            if (idx >= fp.tier1_items) break;
+            const uint32_t pix = fp.heavy_pixels[idx];
+            const int lrow = (int)(pix / (uint32_t)fp.nx), i = (int)(pix - (uint32_t)lrow * (uint32_t)fp.nx);
+            const int j = local_to_global_row(fp, lrow);
+            const rt_pixel_state st = fp.state_in[pix];
+            rt_xorwow pg;
+            pg.v0 = st.rng[0]; pg.v1 = st.rng[1]; pg.v2 = st.rng[2]; pg.v3 = st.rng[3]; pg.v4 = st.rng[4]; pg.d = st.rng[5];
+            f3 pcol = mk3(st.col[0], st.col[1], st.col[2]);
+            unsigned int pixel_rays = 0;
+            for (int sidx = fp.sample_begin; sidx < fp.sample_end; ++sidx) {                 // main.cu:119-125
+                const float u = ((float)i + rt_xorwow_uniform(pg)) / (float)fp.nx;
+                const float v = ((float)j + rt_xorwow_uniform(pg)) / (float)fp.ny;
+                Ray r = camera_get_ray(sd.camera, u, v, pg);
+                f3 thr = mk3(1, 1, 1), rad = mk3(0, 0, 0);
+                for (int depth = 0; depth < 50; ++depth) {                                   // main.cu:54-84
+                    HitInfo h;
+                    ++pixel_rays;
+                    if (!trace_wide<SPHERES_ONLY>(sc, r, h)) { rad = rad + thr * miss_color(fp, r); break; }
+                    const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, r, h);
+                    f3 emitted, attenuation;
+                    Ray scattered;
+                    const bool go_on = shade<TEX>(sc, r, rec, pg, emitted, attenuation, scattered);
+                    rad = rad + thr * emitted;
+                    if (!go_on) break;
+                    thr = thr * attenuation;
+                    r = scattered;
+                }
+                pcol = pcol + rad;
+            }
+            if ((threadIdx.x & 63) == 0) { store_pixel(fp, i, lrow, pcol); rays += pixel_rays; }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        sparse = false;   // tier-1 queue drained: this wave becomes an ordinary wave
+    }
     // A sparse wave's few lanes are on the frame's critical path: let it win instruction-issue arbitration against the
     // three ordinary waves sharing its SIMD (priority outranks age, MI355X_MICROARCH.md "Two waves per SIMD").
     if (sparse && fp.sparse_priority > 0) {
@@ -967,7 +1055,8 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
         DIAG_ADD(0, 1);
         // ---------------- stage A: node steps
         if (__ballot(!finite_inv && (unsigned)node < (unsigned)n_nodes) == 0ull) {
-            for (int step = 0; step < fp.steps_per_trip; ++step) {
+            const int trip_steps = sparse ? 2 * fp.steps_per_trip : fp.steps_per_trip;
+            for (int step = 0; step < trip_steps; ++step) {
                 // nobody left walking (all parked or finished): end the trip now -- this is what keeps the latency of
                 // a wave's last few live lanes near one node step per step (end of frame, small multi-GPU partitions)
                 if (__ballot((unsigned)node < (unsigned)n_nodes) == 0ull) break;
@@ -1032,7 +1121,16 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                     const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, best);
                     const rt_material m = sc.materials[rec.mat];
                     if (m.kind == RT_MAT_DIELECTRIC) {
-                        node = ST_DIEL;
+                        if (sparse) {
+                            // a sparse wave's pixels are mostly glass: scatter here instead of queueing for stage D
+                            // (saves a second resolve_hit and a stage round trip on the frame's critical chain)
+                            const f3 dir = dielectric_direction(cur.d, rec.n, m.ior, g);
+                            ++bounce;
+                            if (bounce >= 50) node = ST_NEWPATH;
+                            else { cur.o = rec.p; cur.d = dir; node = ST_SETUP; }   // attenuation (1,1,1): throughput unchanged
+                        } else {
+                            node = ST_DIEL;
+                        }
                     } else if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
                         const f3 emitted = (TEX > 0 && m.tex >= 0) ? texture_value<TEX>(sc, m.tex, rec.u, rec.v, rec.p) : ld3(m.albedo);
                         radiance = radiance + throughput * emitted;         // main.cu:71, scatter() false
@@ -1092,28 +1190,50 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                     if (!first) { col = col + radiance; ++sample; }
                     first = false;
                     bool alive = true;
-                    if (have_pixel && sample >= fp.ns) {
-                        if (fp.tile_cost) {   // cost prepass: rays this pixel traced, summed per 8x8 tile; no pixel is written
-                            atomicAdd(&fp.tile_cost[(px_lrow >> 3) * fp.tiles_x + (px_i >> 3)], rays - rays_at_pixel_start);
+                    if (have_pixel && sample >= fp.sample_end) {
+                        if (fp.state_out) {
+                            // first part of a split frame: park the pixel at this sample boundary (no path is in flight
+                            // here, so the XORWOW state and the colour sum are the whole state) and record what it cost
+                            const unsigned int c = rays - rays_at_pixel_start;
+                            rt_pixel_state st;
+                            st.rng[0] = g.v0; st.rng[1] = g.v1; st.rng[2] = g.v2; st.rng[3] = g.v3; st.rng[4] = g.v4; st.rng[5] = g.d;
+                            st.col[0] = col.x; st.col[1] = col.y; st.col[2] = col.z; st.cost = c;
+                            fp.state_out[(size_t)px_lrow * fp.nx + px_i] = st;
+                            atomicAdd(&fp.tile_cost[(px_lrow >> 3) * fp.tiles_x + (px_i >> 3)], c);
                         } else {
                             store_pixel(fp, px_i, px_lrow, col);
                         }
                         have_pixel = false;
                     }
                     while (!have_pixel && alive) {
-                        uint32_t w;
+                        bool ok;
                         if (sparse) {
+                            // heavy list (sorted by descending cost): tier 1 = its first tier1_items entries
+                            // tier 2 of the heavy list (tier 1 is served by the plain loop at the top of the kernel)
                             if (((threadIdx.x & 63) % (unsigned)fp.sparse_stride) != 0u) { alive = false; break; }
-                            w = atomicAdd(fp.work_counter + 1, 1u);                 // heavy queue: items [0, heavy_items)
-                            if (w >= fp.heavy_items) { alive = false; break; }
+                            const uint32_t at = fp.tier1_items + atomicAdd(fp.work_counter + 1, 1u);
+                            if (at >= fp.heavy_items) { alive = false; break; }
+                            const uint32_t pix = fp.heavy_pixels[at];
+                            px_lrow = (int)(pix / (uint32_t)fp.nx); px_i = (int)(pix - (uint32_t)px_lrow * (uint32_t)fp.nx);
+                            ok = true;
                         } else {
-                            w = fp.heavy_items + atomicAdd(fp.work_counter, 1u);     // everything after the heavy tiles
+                            const uint32_t w = atomicAdd(fp.work_counter, 1u);
                             if (w >= fp.work_items) { alive = false; break; }
+                            ok = work_to_pixel(fp, w, px_i, px_lrow);
+                            // pixels in the heavy list belong to the sparse waves
+                            if (ok && fp.heavy_items && fp.state_in[(size_t)px_lrow * fp.nx + px_i].cost >= fp.heavy_threshold) ok = false;
                         }
-                        if (work_to_pixel(fp, w, px_i, px_lrow)) {
+                        if (ok) {
                             px_j = local_to_global_row(fp, px_lrow);
-                            rt_xorwow_seed(g, fp.seed_base + (uint64_t)(px_j * fp.nx + px_i));
-                            col = mk3(0, 0, 0); sample = 0; have_pixel = true;
+                            if (fp.state_in) {   // second part of a split frame: pick the pixel up where the first part left it
+                                const rt_pixel_state st = fp.state_in[(size_t)px_lrow * fp.nx + px_i];
+                                g.v0 = st.rng[0]; g.v1 = st.rng[1]; g.v2 = st.rng[2]; g.v3 = st.rng[3]; g.v4 = st.rng[4]; g.d = st.rng[5];
+                                col = mk3(st.col[0], st.col[1], st.col[2]);
+                            } else {
+                                rt_xorwow_seed(g, fp.seed_base + (uint64_t)(px_j * fp.nx + px_i));
+                                col = mk3(0, 0, 0);
+                            }
+                            sample = fp.sample_begin; have_pixel = true;
                             rays_at_pixel_start = rays;
                         }
                     }
@@ -1528,6 +1648,23 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
 #endif
 #undef SF
 #undef SI
+}
+
+// Heavy-pixel list for the cost-aware schedule: every pixel whose prepass ray count reaches `threshold` is appended as
+// (cost << 32 | pixel); the host sorts the (short) list by descending cost.
+__global__ void rt_collect_heavy_kernel(const rt_pixel_state* state, unsigned int n_pixels, unsigned int threshold,
+                                        unsigned long long* list, unsigned int capacity, unsigned int* count) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const unsigned int c = state[i].cost;
+    if (c >= threshold) {
+        const unsigned int at = atomicAdd(count, 1u);
+        if (at < capacity) list[at] = ((unsigned long long)c << 32) | i;
+    }
+}
+void rt_launch_collect_heavy(const rt_pixel_state* state, unsigned int n_pixels, unsigned int threshold, unsigned long long* list,
+                             unsigned int capacity, unsigned int* count, hipStream_t st) {
+    hipLaunchKernelGGL(rt_collect_heavy_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, st, state, n_pixels, threshold, list, capacity, count);
 }
 
 // ------------------------------------------------------------------ launch table

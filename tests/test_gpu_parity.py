@@ -31,9 +31,9 @@ DEFAULT_KERNEL = 3
 
 def render(art, hs, kernel=DEFAULT_KERNEL, opts=None, **frame_kw):
     art.set_option("kernel", kernel)
-    defaults = {"lds_mode": -1, "steps_per_trip": 8, "shade_threshold": 24, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512,
-                "diel_threshold": 2, "newpath_threshold": 16, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1,
-                "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 20, "heavy_max_tiles": 0, "sparse_wg_percent": 35, "sparse_priority": 3,
+    defaults = {"lds_mode": -1, "steps_per_trip": 12, "shade_threshold": 32, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512,
+                "diel_threshold": 2, "newpath_threshold": 24, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1,
+                "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 40, "heavy_max_tiles": 0, "tier1_pixels": 256, "tier1_factor_x10": 70, "split_samples": 32, "sparse_wg_percent": 35, "sparse_priority": 3,
                 "sparse_eager": 0}
     defaults.update(opts or {})
     for k, v in defaults.items():
@@ -115,9 +115,10 @@ def test_empty_partition(gpu):
 def test_scheduling_knobs_do_not_change_pixels(gpu):
     """Everything the scheduler does is re-ordering: LDS residency, trip length, thresholds, workgroup shape."""
     hs = gpu.HostScene("bouncing", 128, 80)
-    base, st0 = render(gpu, hs, 0, ns=6)
+    base, st0 = render(gpu, hs, 0, ns=6)   # ns = 6 with split_samples <= 3 exercises the split-frame schedule
     variants = [(3, {}), (3, {"lpt": 0}), (3, {"sparse_stride": 0}), (3, {"sparse_stride": 64, "heavy_factor_x10": 10, "sparse_wg_percent": 100}),
-                (3, {"sparse_stride": 2, "heavy_factor_x10": 12, "sparse_priority": 0, "sparse_eager": 1}), (3, {"heavy_max_tiles": 3, "sparse_stride": 16}),
+                (3, {"sparse_stride": 2, "heavy_factor_x10": 12, "sparse_priority": 0, "sparse_eager": 1}), (3, {"tier1_pixels": 0, "sparse_stride": 16}),
+                (3, {"split_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096}), (3, {"split_samples": 3, "tier1_factor_x10": 15}),
                 (3, {"lds_mode": 0}), (3, {"lds_mode": 1}), (3, {"steps_per_trip": 1, "shade_threshold": 1, "diel_threshold": 1, "newpath_threshold": 1}),
                 (3, {"steps_per_trip": 11, "shade_threshold": 64, "diel_threshold": 64, "newpath_threshold": 64}), (3, {"threads": 256, "wg_per_cu": 3}),
                 (3, {"threads": 64, "wg_per_cu": 8, "shade_threshold": 40, "newpath_threshold": 3}),
@@ -239,3 +240,19 @@ def test_drop_in_executable_writes_the_reference_ppm(gpu, orc, tmp_path):
         assert np.array_equal(got, want), name
     r = subprocess.run([exe, "--scene", "nope"], capture_output=True, timeout=60)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("name,nx,ny,ns", [("bouncing", 160, 96, 16), ("cornell", 96, 96, 12), ("final", 80, 80, 8)])
+def test_split_frame_schedule_matches_oracle(gpu, orc, name, nx, ny, ns):
+    """The cost-aware schedule (frame split at a sample boundary, pixels parked and resumed, heavy pixels on sparse and
+    single-pixel wide-traversal waves) is scheduling only: with aggressive settings every kind of wave is exercised and
+    the frame must still equal the oracle bit for bit."""
+    img, iw, ih = gpu.default_texture(name)
+    hs = gpu.HostScene(name, nx, ny, img, iw, ih)
+    ref, cnt = orc.OracleScene(name, nx, ny, img, iw, ih).render(ns)
+    for opts in ({"split_samples": 4, "heavy_factor_x10": 15, "tier1_factor_x10": 25, "tier1_pixels": 64, "sparse_stride": 8},
+                 {"split_samples": 2, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096, "sparse_wg_percent": 100},
+                 {"split_samples": 3, "heavy_factor_x10": 12, "tier1_pixels": 0, "sparse_stride": 32, "sparse_priority": 0}):
+        fb, st = render(gpu, hs, 3, opts, ns=ns)
+        assert st.rays == cnt["rays"], (opts, st.rays, cnt["rays"])
+        assert_frames_equal(fb, ref, f"{name} {opts}")
