@@ -31,6 +31,8 @@ int opt_wg_per_cu = 2;
 int opt_leaf_threshold = 1;
 int opt_threads = RT_PERSISTENT_THREADS;
 int opt_diel_threshold = 2;
+int opt_box_threshold = 8;
+int opt_medium_threshold = 16;
 int opt_newpath_threshold = 24;
 int opt_sparse_stride = 8;      // lanes per pixel in sparse waves (64 / live lanes); 0 disables sparse waves
 int opt_split_samples = 32;      // samples per pixel rendered before pixels are ranked by measured cost
@@ -242,6 +244,8 @@ rt_status rt_set_option(const char* key, int value) {
     const std::string k(key);
     if (k == "kernel") { if (value < RT_KERNEL_PIXEL || value > RT_KERNEL_WAVEFRONT) return invalid("kernel: 0..4"); opt_kernel = value; }
     else if (k == "leaf_threshold") { if (value < 1 || value > 64) return invalid("leaf_threshold: 1..64"); opt_leaf_threshold = value; }
+    else if (k == "box_threshold") { if (value < 1 || value > 64) return invalid("box_threshold: 1..64"); opt_box_threshold = value; }
+    else if (k == "medium_threshold") { if (value < 1 || value > 64) return invalid("medium_threshold: 1..64"); opt_medium_threshold = value; }
     else if (k == "diel_threshold") { if (value < 1 || value > 64) return invalid("diel_threshold: 1..64"); opt_diel_threshold = value; }
     else if (k == "newpath_threshold") { if (value < 1 || value > 64) return invalid("newpath_threshold: 1..64"); opt_newpath_threshold = value; }
     else if (k == "sparse_stride") { if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return invalid("sparse_stride: 0, 2, 4, ... 64"); opt_sparse_stride = value; }
@@ -417,6 +421,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     fp.shade_threshold = opt_shade_threshold;
     fp.leaf_threshold = opt_leaf_threshold;
     fp.diel_threshold = opt_diel_threshold;
+    fp.box_threshold = opt_box_threshold; fp.medium_threshold = opt_medium_threshold;
     fp.newpath_threshold = opt_newpath_threshold;
 
     // LDS residency: nodes + spheres if two workgroups still fit a CU, else nodes only, else none

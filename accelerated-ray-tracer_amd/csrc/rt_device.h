@@ -65,6 +65,7 @@ struct rt_frame_params {
     int32_t steps_per_trip;               // persistent kernel: node visits between ballots
     int32_t shade_threshold;              // persistent kernel: waiting lanes that trigger shading
     int32_t leaf_threshold;               // parked kernel: parked lanes that trigger the leaf pass
+    int32_t box_threshold, medium_threshold;   // staged kernel, general scenes: parked box/instance and medium lanes that trigger their leaf tests
     int32_t diel_threshold;               // staged kernel: dielectric hits that trigger their stage
     int32_t newpath_threshold;            // staged kernel: ended paths that trigger the new-path stage
     int32_t wf_slots;                     // wavefront kernel: ray slots per workgroup (multiple of 64)

@@ -1089,10 +1089,46 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
         }
         // ---------------- stage B: leaf pass for parked lanes
         DIAG_ADD(3, __ballot(node < 0) != 0ull); DIAG_ADD(4, __popcll(__ballot(node < 0)));
-        if (node < 0) {
-            leaf_test<SPHERES_ONLY>(sc, parked, cur, tmin, best);
-            parked = -1;
-            node = ~node;
+        if (SPHERES_ONLY) {
+            if (node < 0) {
+                leaf_test<true>(sc, parked, cur, tmin, best);
+                parked = -1;
+                node = ~node;
+            }
+        } else {
+            // General scenes: spheres and quads are served every trip; boxes / instances (six quad tests, a transform)
+            // and media (two boundary tests, a private XORWOW, a logarithm) are long, so their lanes stay parked until a
+            // ballot finds enough of them -- or nobody is left who could step.
+            const int kind = node < 0 ? RT_PRIM_KIND(parked) : -1;
+            if (kind == RT_PRIM_SPHERE || kind == RT_PRIM_QUAD) {
+                float t;
+                const bool hit = kind == RT_PRIM_SPHERE ? sphere_test(sc.spheres[RT_PRIM_INDEX(parked)], cur, tmin, best.t, t)
+                                                        : quad_test(sc.quads[RT_PRIM_INDEX(parked)], cur, tmin, best.t, t);
+                if (hit) { best.t = t; best.prim = parked; best.inst = -1; }
+                parked = -1;
+                node = ~node;
+            }
+            const bool nobody_steps = __ballot((unsigned)node < (unsigned)n_nodes) == 0ull;
+            const int live_b = __popcll(__ballot(node != ST_DEAD));
+            const unsigned long long box_mask = __ballot(kind == RT_PRIM_BOX || kind == RT_PRIM_INSTANCE);
+            if (box_mask != 0ull && (nobody_steps || __popcll(box_mask) >= 1 + ((fp.box_threshold - 1) * live_b >> 6))) {
+                if (kind == RT_PRIM_BOX || kind == RT_PRIM_INSTANCE) {
+                    float t;
+                    int32_t leaf = parked, inst = -1;
+                    if (solid_test(sc, parked, cur, tmin, best.t, t, leaf, inst)) { best.t = t; best.prim = leaf; best.inst = inst; }
+                    parked = -1;
+                    node = ~node;
+                }
+            }
+            const unsigned long long med_mask = __ballot(kind == RT_PRIM_MEDIUM);
+            if (med_mask != 0ull && (nobody_steps || __popcll(med_mask) >= 1 + ((fp.medium_threshold - 1) * live_b >> 6))) {
+                if (kind == RT_PRIM_MEDIUM) {
+                    float t;
+                    if (medium_test(sc, sc.media[RT_PRIM_INDEX(parked)], cur, tmin, best.t, t)) { best.t = t; best.prim = parked; best.inst = -1; }
+                    parked = -1;
+                    node = ~node;
+                }
+            }
         }
         // a finished walk that hit nothing (main.cu:57-68) needs no stage: add the background and end the path now
         if (node == ST_DONE && best.prim < 0) {

@@ -32,7 +32,7 @@ DEFAULT_KERNEL = 3
 def render(art, hs, kernel=DEFAULT_KERNEL, opts=None, **frame_kw):
     art.set_option("kernel", kernel)
     defaults = {"lds_mode": -1, "steps_per_trip": 12, "shade_threshold": 32, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512,
-                "diel_threshold": 2, "newpath_threshold": 24, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1,
+                "diel_threshold": 2, "box_threshold": 8, "medium_threshold": 16, "newpath_threshold": 24, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1,
                 "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 40, "heavy_max_tiles": 0, "tier1_pixels": 256, "tier1_factor_x10": 70, "split_samples": 32, "sparse_wg_percent": 35, "sparse_priority": 3,
                 "sparse_eager": 0}
     defaults.update(opts or {})

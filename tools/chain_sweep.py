@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import accelerated_ray_tracer_amd as art
 ns = int(sys.argv[1]); cfgs = sys.argv[2:]
-DEF = {"kernel": 3, "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 40, "heavy_max_tiles": 0, "tier1_pixels": 256, "tier1_factor_x10": 70, "split_samples": 32, "sparse_wg_percent": 35, "sparse_eager": 0, "sparse_priority": 3, "steps_per_trip": 12, "shade_threshold": 32, "newpath_threshold": 24, "diel_threshold": 2, "threads": 512, "wg_per_cu": 2, "lds_mode": -1}
+DEF = {"kernel": 3, "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 40, "heavy_max_tiles": 0, "tier1_pixels": 256, "tier1_factor_x10": 70, "split_samples": 32, "sparse_wg_percent": 35, "sparse_eager": 0, "sparse_priority": 3, "steps_per_trip": 12, "shade_threshold": 32, "newpath_threshold": 24, "diel_threshold": 2, "box_threshold": 8, "medium_threshold": 16, "threads": 512, "wg_per_cu": 2, "lds_mode": -1}
 art.init(0)
 hs = art.HostScene("random_scene", 1200, 800); ds = art.DeviceScene(hs)
 buf = torch.zeros((800, 1200, 3), dtype=torch.float32, device="cuda")
