@@ -87,7 +87,7 @@ struct rt_scene {
     std::vector<void*> allocs;
     bool spheres_only = false, need_uv = false;
     int tex_level = 0;
-    size_t node_bytes = 0, sphere_bytes = 0;
+    size_t node_bytes = 0, sphere_bytes = 0, shade_bytes = 0;   // shade_bytes: materials + textures
     // per-frame resources
     unsigned long long* d_ray_counter = nullptr;
     unsigned int* d_work_counter = nullptr;
@@ -263,7 +263,7 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "wf_wg_per_cu") { if (value < 1 || value > 8) return invalid("wf_wg_per_cu: 1..8"); opt_wf_wg_per_cu = value; }
     else if (k == "wf_pause_lanes") { if (value < 1 || value > 64) return invalid("wf_pause_lanes: 1..64"); opt_wf_pause_lanes = value; }
     else if (k == "threads") { if (value != 64 && value != 128 && value != 256 && value != 512) return invalid("threads: 64, 128, 256 or 512"); opt_threads = value; }
-    else if (k == "lds_mode") { if (value < -1 || value > 2) return invalid("lds_mode: -1..2"); opt_lds_mode = value; }
+    else if (k == "lds_mode") { if (value < -1 || value > 3) return invalid("lds_mode: -1..3"); opt_lds_mode = value; }
     else if (k == "steps_per_trip") { if (value < 1 || value > 64) return invalid("steps_per_trip: 1..64"); opt_steps_per_trip = value; }
     else if (k == "shade_threshold") { if (value < 1 || value > 64) return invalid("shade_threshold: 1..64"); opt_shade_threshold = value; }
     else if (k == "wg_per_cu") { if (value < 1 || value > 8) return invalid("wg_per_cu: 1..8"); opt_wg_per_cu = value; }
@@ -319,6 +319,8 @@ rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
 #undef UP
     s->dev.n_nodes = d->n_nodes;
     s->dev.n_spheres = d->n_spheres;
+    s->dev.n_materials = d->n_materials; s->dev.n_textures = d->n_textures;
+    s->shade_bytes = (size_t)d->n_materials * sizeof(rt_material) + (size_t)d->n_textures * sizeof(rt_texture);
     s->dev.camera = d->camera;
     s->node_bytes = (size_t)d->n_nodes * sizeof(rt_node);
     s->sphere_bytes = (size_t)d->n_spheres * sizeof(rt_sphere);
@@ -428,15 +430,18 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     int lds_mode = opt_lds_mode;
     const size_t budget2 = g_lds_per_cu / 2 - 1024, budget1 = g_lds_per_cu - 2048;
     if (lds_mode < 0) {
+        // (lds_mode 3 -- materials and textures in LDS too -- is selectable but measured no faster: profiles/r01_sweep34)
         if (s->node_bytes + s->sphere_bytes <= budget2) lds_mode = 2;
         else if (s->node_bytes <= budget2) lds_mode = 1;
         else if (s->node_bytes + s->sphere_bytes <= budget1) lds_mode = 2;
         else if (s->node_bytes <= budget1) lds_mode = 1;
         else lds_mode = 0;
     }
+    if (lds_mode == 3 && opt_kernel != RT_KERNEL_STAGED) lds_mode = 2;
     size_t lds_bytes = 0;
     if (lds_mode >= 1) lds_bytes += s->node_bytes;
     if (lds_mode >= 2) lds_bytes += s->sphere_bytes;
+    if (lds_mode >= 3) lds_bytes += s->shade_bytes;
     if (lds_bytes > budget1) return invalid("requested lds_mode does not fit the CU's LDS");
 
     // the wavefront kernel covers spheres-only scenes with inline/solid/checker textures and frames whose

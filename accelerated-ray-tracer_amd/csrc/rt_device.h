@@ -31,7 +31,7 @@ struct rt_scene_dev {
     const rt_material* materials;
     const rt_texture* textures;
     const uint8_t* images;
-    int32_t n_nodes, n_spheres;
+    int32_t n_nodes, n_spheres, n_materials, n_textures;
     rt_camera camera;
 };
 

@@ -561,6 +561,18 @@ DEV SceneView stage_scene(const rt_scene_dev& sd, unsigned char* lds) {
             const int m16 = sd.n_spheres * 2;
             for (int k = threadIdx.x; k < m16; k += blockDim.x) dst2[k] = src2[k];
             v.spheres = reinterpret_cast<const rt_sphere*>(dst2);
+            if (LDS_MODE >= 3) {   // materials + textures too: one to three dependent L2 round trips less per shaded hit
+                float4* dst3 = dst2 + m16;
+                const float4* src3 = reinterpret_cast<const float4*>(sd.materials);
+                const int q16 = sd.n_materials * 2;
+                for (int k = threadIdx.x; k < q16; k += blockDim.x) dst3[k] = src3[k];
+                v.materials = reinterpret_cast<const rt_material*>(dst3);
+                float4* dst4 = dst3 + q16;
+                const float4* src4 = reinterpret_cast<const float4*>(sd.textures);
+                const int r16 = sd.n_textures * 4;
+                for (int k = threadIdx.x; k < r16; k += blockDim.x) dst4[k] = src4[k];
+                v.textures = reinterpret_cast<const rt_texture*>(dst4);
+            }
         }
         __syncthreads();
     }
@@ -1729,7 +1741,13 @@ void launch_variant(int kernel, const rt_scene_dev& sd, const rt_frame_params& f
 
 template <bool SO, int TX, bool UV>
 void launch_lds(int kernel, int lds_mode, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    if (lds_mode == 2) launch_variant<SO, TX, UV, 2>(kernel, sd, fp, grid, block, lds, st);
+    if (lds_mode == 3 && kernel == RT_KERNEL_STAGED) {   // only the shipping kernel carries the materials-in-LDS variant
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_render_staged_kernel<SO, TX, UV, 3>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((rt_render_staged_kernel<SO, TX, UV, 3>), grid, block, lds, st, sd, fp);
+        return;
+    }
+    if (lds_mode >= 2) launch_variant<SO, TX, UV, 2>(kernel, sd, fp, grid, block, lds, st);
     else if (lds_mode == 1) launch_variant<SO, TX, UV, 1>(kernel, sd, fp, grid, block, lds, st);
     else launch_variant<SO, TX, UV, 0>(kernel, sd, fp, grid, block, lds, st);
 }

@@ -119,7 +119,7 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
     variants = [(3, {}), (3, {"lpt": 0}), (3, {"sparse_stride": 0}), (3, {"sparse_stride": 64, "heavy_factor_x10": 10, "sparse_wg_percent": 100}),
                 (3, {"sparse_stride": 2, "heavy_factor_x10": 12, "sparse_priority": 0, "sparse_eager": 1}), (3, {"tier1_pixels": 0, "sparse_stride": 16}),
                 (3, {"split_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096}), (3, {"split_samples": 3, "tier1_factor_x10": 15}),
-                (3, {"lds_mode": 0}), (3, {"lds_mode": 1}), (3, {"steps_per_trip": 1, "shade_threshold": 1, "diel_threshold": 1, "newpath_threshold": 1}),
+                (3, {"lds_mode": 0}), (3, {"lds_mode": 3}), (3, {"lds_mode": 1}), (3, {"steps_per_trip": 1, "shade_threshold": 1, "diel_threshold": 1, "newpath_threshold": 1}),
                 (3, {"steps_per_trip": 11, "shade_threshold": 64, "diel_threshold": 64, "newpath_threshold": 64}), (3, {"threads": 256, "wg_per_cu": 3}),
                 (3, {"threads": 64, "wg_per_cu": 8, "shade_threshold": 40, "newpath_threshold": 3}),
                 (4, {}), (4, {"wf_threads": 1024, "lds_mode": 1}), (4, {"wf_threads": 256, "wf_slots": 384, "wf_wg_per_cu": 3, "lds_mode": 0, "wf_pause_lanes": 64}),

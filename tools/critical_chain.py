@@ -19,7 +19,7 @@ print(f"whole frame @ {ns} spp: {st.ms_render:.2f} ms, {st.rays} rays  opts {opt
 res = []
 for band in range(0, 100, 3):
     _, sb = ds.render(hs.frame(ns=ns, tile_rows=8, tile_first=band, tile_stride=10**6), out=buf.data_ptr(), blocking=True)
-    res.append((sb.ms_render, band, sb.rays))
+    res.append((sb.ms_render, band, sb.rays, sb.reserved, sb.workgroups))
 res.sort(reverse=True)
-for ms, band, rays in res[:6]: print(f"  rows {band*8:3d}..{band*8+7:3d}: {ms:8.2f} ms   {rays/(1200*8*ns):5.2f} rays/sample")
+for ms, band, rays, heavy, wgs in res[:6]: print(f"  rows {band*8:3d}..{band*8+7:3d}: {ms:8.2f} ms   {rays/(1200*8*ns):5.2f} rays/sample   heavy pixels {heavy}  workgroups {wgs}")
 print(f"  median band {np.median([r[0] for r in res]):.2f} ms")
