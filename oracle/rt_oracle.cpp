@@ -7,14 +7,28 @@
 // library, and only as the checker.  Nothing under accelerated-ray-tracer_amd/
 // includes, links or calls it.
 //
-// PARITY UNPINNED: the reference has no tests, golden vectors or fixtures
+// PINNING.  The reference has no tests, golden vectors or fixtures
 //  and cannot be built here (it needs nvcc and cuRAND's
 // curand_kernel.h, neither of which is in this image; building it against
-// stand-in headers is not allowed).  The XORWOW constants below restate the
-// published cuRAND algorithm from memory.  The only outside pins are the
-// counters SURVEY.md section 8 recorded from the reference's own code
-// (scene structure, rays per sample, box tests per ray) -- see
-// tests/golden/survey_pins.json and tests/test_oracle_pins.py.
+// stand-in headers is not allowed).  What the reference does hold is output:
+// its README images (images/*.png) are lossless 8-bit copies of the PPM the
+// CUDA binary printed for nine scene functions of the current source at their
+// own nx, ny, ns and seeds.  This oracle is pinned against those at 8-bit
+// level (tests/test_reference_images.py, tests/golden/reference_image_pins.npz;
+// full-frame rates in profiles/r01_reference_image_match.txt): quads 99.997 %
+// of 720,000 pixels identical and the rest off by one level, checker / earth /
+// perlin / simple_light 97.7-99.6 % identical, the 10000-spp scenes identical
+// until a pixel's sample stream first diverges and noise-equivalent after.
+// That pins the XORWOW stream (restated here from the published cuRAND
+// algorithm), per-pixel seeding, draw order, scene construction, BVH rules,
+// hit routines, materials, textures, camera, accumulation and gamma.
+// NOT pinned: fp32 bit-level parity with a CUDA build -- no fp32 output of the
+// reference exists, nvcc contracts a*b+c into FMA by default and CUDA's
+// transcendentals are not correctly rounded, so "parity unpinned" still
+// applies below the 8-bit level.  Further outside pins: the counters SURVEY.md
+// section 8 recorded from the reference's own code (scene structure, rays per
+// sample, box tests per ray) -- tests/golden/survey_pins.json,
+// tests/test_oracle_pins.py.
 //
 // Floating-point contract of this oracle ("reference semantics"):
 //   * IEEE-754 binary32 for + - * / sqrt, no FMA contraction (build with

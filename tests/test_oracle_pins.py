@@ -1,7 +1,8 @@
-"""The oracle against the only outside pins that exist (tests/golden/survey_pins.json) and its own fixtures.
+"""The oracle against the structural pins (tests/golden/survey_pins.json) and its own fixtures.
 
-PARITY UNPINNED: the reference ships no tests or golden vectors and cannot be built in this image; these pins are
-the counters SURVEY.md recorded from the reference's own device code run on CPU."""
+The reference ships no tests or golden vectors and cannot be built in this image; these pins are the counters
+SURVEY.md recorded from the reference's own device code.  The pixel-level pins (the reference's own output images)
+are in tests/test_reference_images.py."""
 import json
 import os
 

@@ -1,0 +1,142 @@
+"""The oracle and the HIP path against the only outputs of the real CUDA reference that exist: its README images.
+
+tests/golden/reference_image_pins.npz holds pixel rows of /root/reference/images/*.png (made by
+tests/golden/make_reference_image_pins.py).  Each image is the lossless 8-bit copy of the PPM the reference binary
+printed (int(255.99f*c), src/main.cu:715-727) for one scene function of the current source at that function's own
+nx, ny, ns (500 or 10000 spp) with the per-pixel seeds 1984 + pixel_index (main.cu:104).
+
+What can and cannot match.  A pixel's samples are one sequential XORWOW stream, so the two sides agree to the last
+bit until the first sample in which an ulp-level difference (nvcc contracts a*b+c to FMA by default and CUDA's
+sinf/logf/powf are not correctly rounded; this build does neither) flips a branch that draws random numbers; from
+there on that pixel's samples are statistically independent of the reference's.  The measured flip rate is about
+1e-5 per ray, so the 500-spp scenes are 8-bit identical in 98.5-99.997 % of their pixels, and the 10000-spp scenes
+in 8-83 % with the rest differing by Monte-Carlo noise only (the difference to the reference equals the difference
+between two builds of this repo with and without FMA contraction: profiles/r01_reference_image_match.txt).  The
+thresholds below sit just under the measured rates; a wrong RNG stream, draw order, scene constant, BVH rule or
+material would drop them to the independent-noise level or far below.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PINS = np.load(os.path.join(HERE, "golden", "reference_image_pins.npz"))
+META = json.load(open(os.path.join(HERE, "golden", "reference_image_pins.json")))
+TILE_ROWS, TILE_FIRST, TILE_STRIDE = META["tile_rows"], META["tile_first"], META["tile_stride"]
+
+
+def to_8bit(fb):
+    """The reference's output stage: int(255.99f * c), main.cu:722 (values above 255 clip in the PNG)."""
+    return np.clip((fb * np.float32(255.99)).astype(np.int32), 0, 255)
+
+
+def match(rows8, ref8):
+    d = np.abs(rows8.astype(np.int32) - ref8.astype(np.int32))
+    m = d.max(-1)
+    return {"exact": float((m == 0).mean()), "within1": float((m <= 1).mean()), "within2": float((m <= 2).mean()),
+            "mean": float(d.mean()), "max": int(d.max())}
+
+
+# ---- CPU: the oracle on a few pinned rows (whole tiles for the 500-spp scenes, single rows at 10000 spp) ----
+
+# scene: (local tile indices to render, rows per tile to render, min exact, min within1, max mean |d|)
+ORACLE_CASES = {
+    "quads":        ([3, 9, 14], 4, 0.9995, 1.0, 0.001),
+    "checker":      ([3, 9, 14], 4, 0.985, 0.999, 0.02),
+    "earth":        ([6, 9, 12], 4, 0.98, 0.99, 0.05),
+    "perlin":       ([3, 9, 14], 4, 0.93, 0.99, 0.06),
+    "simple_light": ([6], 1, 0.92, 0.998, 0.08),
+    "bouncing":     ([7], 1, 0.55, 0.90, 0.5),
+    "cornell":      ([9], 1, 0.25, 0.80, 1.2),
+}
+
+
+@pytest.mark.parametrize("scene", list(ORACLE_CASES))
+def test_oracle_reproduces_reference_image(art, orc, scene):
+    tiles, nrows, min_exact, min_w1, max_mean = ORACLE_CASES[scene]
+    info = META["images"][scene]
+    nx, ny = info["nx"], info["ny"]
+    img, iw, ih = art.default_texture(scene)
+    o = orc.OracleScene(scene, nx, ny, img, iw, ih)
+    assert (o.def_nx, o.def_ny) == (nx, ny), "the image has the size the reference host function renders"
+    got, ref = [], []
+    for t in tiles:
+        row0 = (TILE_FIRST + t * TILE_STRIDE) * TILE_ROWS
+        fb, _ = o.render(o.def_ns, row0=row0, row1=row0 + nrows)
+        got.append(to_8bit(fb[row0:row0 + nrows]))
+        ref.append(PINS["rows_" + scene][t * TILE_ROWS:t * TILE_ROWS + nrows])
+    s = match(np.concatenate(got), np.concatenate(ref))
+    print(scene, o.def_ns, "spp", s)
+    assert s["exact"] >= min_exact and s["within1"] >= min_w1 and s["mean"] <= max_mean, (scene, s)
+
+
+def test_wrong_seed_does_not_reproduce_the_image(art, orc):
+    """Control: the same scene with another per-pixel seed base is a valid render but not the reference's pixels."""
+    info = META["images"]["quads"]
+    o = orc.OracleScene("quads", info["nx"], info["ny"])
+    row0 = (TILE_FIRST + 9 * TILE_STRIDE) * TILE_ROWS
+    fb, _ = o.render(o.def_ns, seed_base=1985, row0=row0, row1=row0 + TILE_ROWS)
+    s = match(to_8bit(fb[row0:row0 + TILE_ROWS]), PINS["rows_quads"][9 * TILE_ROWS:10 * TILE_ROWS])
+    assert s["exact"] < 0.9 and s["mean"] > 0.2, s
+
+
+# ---- GPU: the HIP path on every pinned row of every image, at the reference's own spp ----
+
+# scene: (min exact, min within1, max mean |d|); measured values are in profiles/r01_reference_image_match.txt
+GPU_CASES = {
+    "quads":        (0.9995, 1.0, 0.001),
+    "checker":      (0.99, 0.999, 0.01),
+    "earth":        (0.99, 0.995, 0.01),
+    "perlin":       (0.975, 0.995, 0.03),
+    "simple_light": (0.96, 0.999, 0.03),
+    "bouncing":     (0.75, 0.95, 0.2),
+    "cornell":      (0.40, 0.90, 0.6),
+    "original":     (0.07, 0.28, 2.6),
+    "final":        (0.06, 0.20, 3.5),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", list(GPU_CASES))
+def test_hip_path_reproduces_reference_image(gpu, scene):
+    min_exact, min_w1, max_mean = GPU_CASES[scene]
+    info = META["images"][scene]
+    img, iw, ih = gpu.default_texture(scene)
+    hs = gpu.HostScene(scene, 0, 0, img, iw, ih)
+    assert (hs.nx, hs.ny) == (info["nx"], info["ny"])
+    ds = gpu.DeviceScene(hs)
+    try:
+        fb, st = ds.render(hs.frame(tile_rows=TILE_ROWS, tile_first=TILE_FIRST, tile_stride=TILE_STRIDE))
+    finally:
+        ds.close()
+    ref = PINS["rows_" + scene]
+    assert fb.shape == ref.shape
+    s = match(to_8bit(fb), ref)
+    print(scene, hs.ns, "spp", st.rays, "rays", s)
+    assert s["exact"] >= min_exact and s["within1"] >= min_w1 and s["mean"] <= max_mean, (scene, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,ns,max_mae,min_corr", [("final", 2500, 1.5, 0.9995), ("original", 2500, 1.5, 0.9995)])
+def test_long_chain_scenes_agree_in_the_mean(gpu, scene, ns, max_mae, min_corr):
+    """The two 10000-spp scenes with media / procedural textures diverge from the reference's sample streams in most
+    pixels (see the module docstring), so their rows only agree to noise.  What must still hold is that the image is
+    a sample of the same distribution: 8x8 box means of the whole frame (64 x ns samples each) against the
+    reference image's box means.  Measured at 10000 spp: MAE 0.47 / 0.39 of 255, correlation 0.9999."""
+    img, iw, ih = gpu.default_texture(scene)
+    hs = gpu.HostScene(scene, 0, 0, img, iw, ih)
+    ds = gpu.DeviceScene(hs)
+    try:
+        fb, _ = ds.render(hs.frame(ns=ns))
+    finally:
+        ds.close()
+    a = to_8bit(fb).astype(np.float32)
+    ny, nx, _ = a.shape
+    box = a.reshape(ny // 8, 8, nx // 8, 8, 3).mean((1, 3))
+    ref = PINS["box_" + scene]
+    mae = float(np.abs(box - ref).mean())
+    corr = float(np.corrcoef(box.ravel(), ref.ravel())[0, 1])
+    print(scene, ns, "spp: box MAE", mae, "corr", corr)
+    assert mae <= max_mae and corr >= min_corr, (mae, corr)
