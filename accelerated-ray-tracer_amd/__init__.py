@@ -25,7 +25,7 @@ PKG_DIR = os.path.dirname(os.path.realpath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 RT_LIB_PATH = os.environ.get("RT_LIB_OVERRIDE") or os.path.join(LIB_DIR, "librt_mi355x.so")   # override: diagnostic builds only
-HOST_LIB_PATH = os.path.join(LIB_DIR, "librtw_host.so")
+HOST_LIB_PATH = os.environ.get("RTW_LIB_OVERRIDE") or os.path.join(LIB_DIR, "librtw_host.so")   # override: experiments only
 
 
 class RtError(RuntimeError):

@@ -50,9 +50,14 @@ DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 DEV f3 operator*(float t, f3 v) { return mk3(t * v.x, t * v.y, t * v.z); }
 DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 DEV f3 sdiv(f3 v, float t) { return mk3(v.x / t, v.y / t, v.z / t); }
-DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x); }
-DEV float length(f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+// Contracted exactly where nvcc's default -fmad=true contracts the reference (DESIGN.md "numerical contract"): a
+// product whose only use is an add/sub becomes one FMA with it; of two products under one add the first is fused;
+// m0 + m1 + m2 = fma(m2, fma(m0, m1)).  The build itself runs with -ffp-contract=off: every FMA is written out.
+DEV float dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.x, b.x, a.y * b.y)); }
+DEV f3 cross(f3 a, f3 b) { return mk3(fmaf(a.y, b.z, -(a.z * b.y)), -fmaf(a.x, b.z, -(a.z * b.x)), fmaf(a.x, b.y, -(a.y * b.x))); }
+DEV float length(f3 v) { return sqrtf(fmaf(v.z, v.z, fmaf(v.x, v.x, v.y * v.y))); }
+DEV f3 fma3(float t, f3 v, f3 a) { return mk3(fmaf(t, v.x, a.x), fmaf(t, v.y, a.y), fmaf(t, v.z, a.z)); }      // a + t*v
+DEV f3 fma3(f3 t, f3 v, f3 a) { return mk3(fmaf(t.x, v.x, a.x), fmaf(t.y, v.y, a.y), fmaf(t.z, v.z, a.z)); }    // a + t*v, per component
 DEV f3 unit_vector(f3 v) { return sdiv(v, length(v)); }
 
 // correctly rounded fp32 transcendentals via double
@@ -68,7 +73,7 @@ DEV float cr_atan2(float y, float x) { return (float)atan2((double)y, (double)x)
 // narrowed to float (sphere.cuh:54 through ray.cuh:16) or copied to the
 // scattered ray, so the narrowed value is carried instead.
 struct Ray { f3 o, d; float tm; };
-DEV f3 ray_at(const Ray& r, float t) { return r.o + t * r.d; }
+DEV f3 ray_at(const Ray& r, float t) { return fma3(t, r.d, r.o); }   // A + t*B: one FMA per component
 
 // what the traversal keeps about the closest hit; everything else is
 // recomputed once per ray by resolve_hit() with the same expressions
@@ -96,12 +101,12 @@ struct SceneView {
 // sphere::hit (sphere.cuh:51-89).  Returns the accepted root or a negative
 // value; exclusive bounds t > tmin && t < tmax.
 DEV bool sphere_test(const rt_sphere& s, const Ray& r, float tmin, float tmax, float& t_out) {
-    const f3 cc = ld3(s.c0) + r.tm * ld3(s.vel);
+    const f3 cc = fma3(r.tm, ld3(s.vel), ld3(s.c0));
     const f3 oc = r.o - cc;
     const float a = dot(r.d, r.d);
     const float b = dot(oc, r.d);
-    const float c = dot(oc, oc) - s.radius * s.radius;
-    const float disc = b * b - a * c;
+    const float c = fmaf(-s.radius, s.radius, dot(oc, oc));
+    const float disc = fmaf(b, b, -(a * c));
     if (disc <= 0.0f) return false;
     const float sq = sqrtf(disc);
     float t = (-b - sq) / a;
@@ -161,8 +166,8 @@ DEV Ray to_object_space(const rt_instance& in, const Ray& r) {
     if (in.flags & RT_INST_ROTATE_Y) {
         const float c = in.cos_t, s = in.sin_t;
         const f3 o = q.o, d = q.d;
-        q.o = mk3(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
-        q.d = mk3(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
+        q.o = mk3(fmaf(c, o.x, -(s * o.z)), o.y, fmaf(s, o.x, c * o.z));
+        q.d = mk3(fmaf(c, d.x, -(s * d.z)), d.y, fmaf(s, d.x, c * d.z));
     }
     return q;
 }
@@ -270,7 +275,7 @@ DEV HitRec resolve_hit(const SceneView& sc, const Ray& r, const HitInfo& h) {
     if (through_instance) { in = sc.instances[h.inst]; q = to_object_space(in, r); }
     if (kind == RT_PRIM_SPHERE) {                           // sphere.cuh:68-74
         const rt_sphere s = sc.spheres[idx];
-        const f3 cc = ld3(s.c0) + q.tm * ld3(s.vel);
+        const f3 cc = fma3(q.tm, ld3(s.vel), ld3(s.c0));
         rec.p = ray_at(q, h.t);
         rec.n = sdiv(rec.p - cc, s.radius);
         if (NEED_UV) sphere_uv(rec.n, rec.u, rec.v);
@@ -289,10 +294,10 @@ DEV HitRec resolve_hit(const SceneView& sc, const Ray& r, const HitInfo& h) {
     if (through_instance) {
         if (in.flags & RT_INST_ROTATE_Y) {                  // hittable.cuh:129-142
             const float c = in.cos_t, s = in.sin_t;
-            const float px = c * rec.p.x + s * rec.p.z;
-            const float pz = -s * rec.p.x + c * rec.p.z;
-            const float nx = c * rec.n.x + s * rec.n.z;
-            const float nz = -s * rec.n.x + c * rec.n.z;
+            const float px = fmaf(c, rec.p.x, s * rec.p.z);
+            const float pz = fmaf(-s, rec.p.x, c * rec.p.z);
+            const float nx = fmaf(c, rec.n.x, s * rec.n.z);
+            const float nz = fmaf(-s, rec.n.x, c * rec.n.z);
             rec.p = mk3(px, rec.p.y, pz);
             rec.n = unit_vector(mk3(nx, rec.n.y, nz));
             // "faces against the original ray": rotate_y::hit sees the translated ray
@@ -308,7 +313,7 @@ DEV HitRec resolve_hit(const SceneView& sc, const Ray& r, const HitInfo& h) {
 DEV uint32_t wanghash(uint32_t x) {
     x = (x ^ 61u) ^ (x >> 16); x *= 9u; x = x ^ (x >> 4); x *= 0x27d4eb2du; x = x ^ (x >> 15); return x;
 }
-DEV float u2m11(uint32_t h) { return (float)((h >> 8) & 0x00FFFFFFu) * (1.0f / 8388607.5f) - 1.0f; }
+DEV float u2m11(uint32_t h) { return fmaf((float)((h >> 8) & 0x00FFFFFFu), (1.0f / 8388607.5f), -1.0f); }
 DEV f3 perlin_grad(int xi, int yi, int zi) {
     const uint32_t h = wanghash((uint32_t)xi * 73856093u ^ (uint32_t)yi * 19349663u ^ (uint32_t)zi * 83492791u);
     return unit_vector(mk3(u2m11(h), u2m11(wanghash(h)), u2m11(wanghash(h ^ 0x9e3779b9u))));
@@ -328,7 +333,7 @@ DEV float perlin_noise(f3 p) {
                 const f3 g = perlin_grad(i + a, j + b, k + c);
                 const f3 weight = mk3(u - (float)a, v - (float)b, w - (float)c);
                 const float s = (a ? uu : (1.0f - uu)) * (b ? vv : (1.0f - vv)) * (c ? ww : (1.0f - ww));
-                accum += s * dot(g, weight);
+                accum = fmaf(s, dot(g, weight), accum);
             }
     return accum;
 }
@@ -336,7 +341,7 @@ DEV float perlin_turb(f3 p, int depth) {
     float accum = 0.0f, weight = 1.0f;
     f3 temp = p;
     for (int i = 0; i < depth; ++i) {
-        accum += weight * perlin_noise(temp);
+        accum = fmaf(weight, perlin_noise(temp), accum);
         weight *= 0.5f;
         temp = mk3(temp.x * 2.0f, temp.y * 2.0f, temp.z * 2.0f);
     }
@@ -377,21 +382,21 @@ DEV f3 texture_value(const SceneView& sc, int tex, float u, float v, f3 p) {
         const f3 dir = mk3(t.p[3], t.p[4], t.p[5]);
         const float uu = dot(p, dir);
         const float wig = perlin_turb(t.p[7] * p, t.a);
-        const float stripes = fabsf(cr_sin(t.scale * uu + t.p[6] * wig));
+        const float stripes = fabsf(cr_sin(fmaf(t.scale, uu, t.p[6] * wig)));
         const float q = clamp01((stripes - 0.75f) / (0.98f - 0.75f));          // smoothstep, texture.cuh:78-82
         const float w = q * q * (3.0f - 2.0f * q);
-        return (1.f - w) * mk3(t.p[0], t.p[1], t.p[2]) + w * ld3(t.color);
+        return fma3(1.f - w, mk3(t.p[0], t.p[1], t.p[2]), w * ld3(t.color));
     }
     if (t.kind == RT_TEX_FELT) {                            // texture.cuh:124-147
         const float m = perlin_noise(t.scale * p);
-        const float phase = p.x * t.p[1] + 2.0f * perlin_turb(0.5f * p, 2);
+        const float phase = fmaf(p.x, t.p[1], 2.0f * perlin_turb(0.5f * p, 2));
         const float fibers = 0.5f * (1.0f + cr_sin(phase));
-        float gain = 1.0f + t.p[0] * (m - 0.5f) + t.p[2] * (fibers - 0.5f);
+        float gain = fmaf(t.p[2], fibers - 0.5f, fmaf(t.p[0], m - 0.5f, 1.0f));
         gain = fminf(fmaxf(gain, 0.7f), 1.2f);
         return gain * ld3(t.color);
     }
     // noise (texture.cuh:67-72)
-    const float s = cr_sin(t.scale * p.z + 10.0f * perlin_turb(p, 7));
+    const float s = cr_sin(fmaf(t.scale, p.z, 10.0f * perlin_turb(p, 7)));
     const float g = 0.5f * (1.0f + s);
     return mk3(g, g, g);
 }
@@ -403,16 +408,18 @@ DEV f3 random_in_unit_sphere(rt_xorwow& g) {
         const float b = 2.0f * rt_xorwow_uniform(g) - 1.0f;
         const float c = 2.0f * rt_xorwow_uniform(g) - 1.0f;
         const f3 p = mk3(a, b, c);
-        if (p.x * p.x + p.y * p.y + p.z * p.z < 1.0f) return p;
+        if (dot(p, p) < 1.0f) return p;
     }
 }
-DEV f3 reflect(f3 v, f3 n) { return v - (2.0f * dot(v, n)) * n; }
+DEV f3 reflect(f3 v, f3 n) { return fma3(-(2.0f * dot(v, n)), n, v); }
 DEV bool refract(f3 v, f3 n, float ni_over_nt, f3& refracted) {
     const f3 uv = unit_vector(v);
     const float dt = dot(uv, n);
-    const float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+    const float disc = fmaf(-(ni_over_nt * ni_over_nt), fmaf(-dt, dt, 1.0f), 1.0f);
     if (disc > 0.0f) {
-        refracted = ni_over_nt * (uv - dt * n) - sqrtf(disc) * n;
+        // ni*(uv - n*dt) - n*sqrt(disc): the second product is the one fused with the subtraction (tuned on the
+        // reference's images)
+        refracted = fma3(-sqrtf(disc), n, ni_over_nt * fma3(-dt, n, uv));
         return true;
     }
     return false;
@@ -420,7 +427,7 @@ DEV bool refract(f3 v, f3 n, float ni_over_nt, f3& refracted) {
 DEV float schlick(float cosine, float ref_idx) {
     float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
     r0 = r0 * r0;
-    return r0 + (1.0f - r0) * cr_pow5(1.0f - cosine);
+    return fmaf(1.0f - r0, cr_pow5(1.0f - cosine), r0);
 }
 
 // dielectric::scatter (material.cuh:119-159): direction of the scattered ray; attenuation is (1,1,1)
@@ -434,7 +441,7 @@ DEV f3 dielectric_direction(f3 d_in, f3 n, float ior, rt_xorwow& g) {
         outward_normal = -n;
         ni_over_nt = ior;
         cosine = d_n / length(d_in);
-        cosine = sqrtf(fmaxf(0.0f, 1.0f - ior * ior * (1.0f - cosine * cosine)));
+        cosine = sqrtf(fmaxf(0.0f, fmaf(-(ior * ior), fmaf(-cosine, cosine, 1.0f), 1.0f)));
     } else {
         outward_normal = n;
         ni_over_nt = 1.0f / ior;
@@ -462,7 +469,7 @@ DEV bool shade(const SceneView& sc, const Ray& in, const HitRec& rec, rt_xorwow&
     case RT_MAT_METAL: {
         const f3 reflected = reflect(unit_vector(in.d), rec.n);
         const f3 rs = random_in_unit_sphere(g);
-        out.d = reflected + m.fuzz * rs;
+        out.d = fma3(m.fuzz, rs, reflected);
         attenuation = ld3(m.albedo);
         return dot(out.d, rec.n) > 0.0f;
     }
@@ -493,12 +500,12 @@ DEV Ray camera_get_ray(const rt_camera& c, float s, float t, rt_xorwow& g) {
     } while (dot(p, p) >= 1.0f);
     const f3 rd = c.lens_radius * p;
     const f3 cu = ld3(c.u), cv = ld3(c.v);
-    const f3 offset = rd.x * cu + rd.y * cv;
-    const double tm = c.time0 + (double)rt_xorwow_uniform(g) * (c.time1 - c.time0);
+    const f3 offset = fma3(rd.x, cu, rd.y * cv);
+    const double tm = fma((double)rt_xorwow_uniform(g), c.time1 - c.time0, c.time0);
     const f3 origin = ld3(c.origin);
     Ray r;
     r.o = origin + offset;
-    r.d = (((ld3(c.lower_left_corner) + s * ld3(c.horizontal)) + t * ld3(c.vertical)) - origin) - offset;
+    r.d = (fma3(t, ld3(c.vertical), fma3(s, ld3(c.horizontal), ld3(c.lower_left_corner))) - origin) - offset;
     r.tm = (float)tm;
     return r;
 }
@@ -514,7 +521,7 @@ DEV f3 miss_color(const rt_frame_params& fp, const Ray& r) {   // main.cu:59-65
     if (fp.use_gradient_bg) {
         const f3 ud = unit_vector(r.d);
         const float t = 0.5f * (ud.y + 1.0f);
-        bg = (1.0f - t) * mk3(1.0f, 1.0f, 1.0f) + t * mk3(0.5f, 0.7f, 1.0f);
+        bg = mk3(fmaf(t, 0.5f, 1.0f - t), fmaf(t, 0.7f, 1.0f - t), (1.0f - t) + t);   // (1-t)*1 folds to (1-t), t*1 to t
     }
     return bg;
 }
@@ -675,14 +682,14 @@ __global__ void __launch_bounds__(256) rt_render_pixel_kernel(rt_scene_dev sd, r
                 HitInfo h;
                 ++rays;
                 if (!trace<SPHERES_ONLY>(sc, cur, h)) {
-                    radiance = radiance + throughput * miss_color(fp, cur);
+                    radiance = fma3(throughput, miss_color(fp, cur), radiance);
                     break;
                 }
                 const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, h);
                 f3 emitted, attenuation;
                 Ray scattered;
                 const bool go_on = shade<TEX>(sc, cur, rec, g, emitted, attenuation, scattered);
-                radiance = radiance + throughput * emitted;
+                radiance = fma3(throughput, emitted, radiance);
                 if (!go_on) break;
                 throughput = throughput * attenuation;
                 cur = scattered;
@@ -754,14 +761,14 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS) rt_render_persistent_ke
             if (pending_hit) {
                 pending_hit = false;
                 if (best.prim < 0) {                                   // miss (main.cu:57-68)
-                    radiance = radiance + throughput * miss_color(fp, cur);
+                    radiance = fma3(throughput, miss_color(fp, cur), radiance);
                     need_sample = true;
                 } else {
                     const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, best);
                     f3 emitted, attenuation;
                     Ray scattered;
                     const bool go_on = shade<TEX>(sc, cur, rec, g, emitted, attenuation, scattered);
-                    radiance = radiance + throughput * emitted;        // main.cu:71
+                    radiance = fma3(throughput, emitted, radiance);        // main.cu:71
                     ++bounce;
                     if (!go_on || bounce >= 50) need_sample = true;    // main.cu:54,76-80
                     else { throughput = throughput * attenuation; cur = scattered; }
@@ -906,14 +913,14 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
             if (pending_hit) {
                 pending_hit = false;
                 if (best.prim < 0) {
-                    radiance = radiance + throughput * miss_color(fp, cur);
+                    radiance = fma3(throughput, miss_color(fp, cur), radiance);
                     need_sample = true;
                 } else {
                     const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, best);
                     f3 emitted, attenuation;
                     Ray scattered;
                     const bool go_on = shade<TEX>(sc, cur, rec, g, emitted, attenuation, scattered);
-                    radiance = radiance + throughput * emitted;
+                    radiance = fma3(throughput, emitted, radiance);
                     ++bounce;
                     if (!go_on || bounce >= 50) need_sample = true;
                     else { throughput = throughput * attenuation; cur = scattered; }
@@ -1038,12 +1045,12 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                 for (int depth = 0; depth < 50; ++depth) {                                   // main.cu:54-84
                     HitInfo h;
                     ++pixel_rays;
-                    if (!trace_wide<SPHERES_ONLY>(sc, r, h)) { rad = rad + thr * miss_color(fp, r); break; }
+                    if (!trace_wide<SPHERES_ONLY>(sc, r, h)) { rad = fma3(thr, miss_color(fp, r), rad); break; }
                     const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, r, h);
                     f3 emitted, attenuation;
                     Ray scattered;
                     const bool go_on = shade<TEX>(sc, r, rec, pg, emitted, attenuation, scattered);
-                    rad = rad + thr * emitted;
+                    rad = fma3(thr, emitted, rad);
                     if (!go_on) break;
                     thr = thr * attenuation;
                     r = scattered;
@@ -1144,7 +1151,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
         }
         // a finished walk that hit nothing (main.cu:57-68) needs no stage: add the background and end the path now
         if (node == ST_DONE && best.prim < 0) {
-            radiance = radiance + throughput * miss_color(fp, cur);
+            radiance = fma3(throughput, miss_color(fp, cur), radiance);
             node = ST_NEWPATH;
         }
         const unsigned long long walking = __ballot(node < n_nodes);
@@ -1181,7 +1188,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                         }
                     } else if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
                         const f3 emitted = (TEX > 0 && m.tex >= 0) ? texture_value<TEX>(sc, m.tex, rec.u, rec.v, rec.p) : ld3(m.albedo);
-                        radiance = radiance + throughput * emitted;         // main.cu:71, scatter() false
+                        radiance = fma3(throughput, emitted, radiance);         // main.cu:71, scatter() false
                         node = ST_NEWPATH;
                     } else {
                         // lambertian / metal / isotropic: one shared rejection loop (material.cuh:12-18)
@@ -1190,7 +1197,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                         bool go_on = true;
                         if (m.kind == RT_MAT_METAL) {                       // material.cuh:99-109
                             const f3 reflected = reflect(unit_vector(cur.d), rec.n);
-                            dir = reflected + m.fuzz * rs;
+                            dir = fma3(m.fuzz, rs, reflected);
                             attenuation = ld3(m.albedo);
                             go_on = dot(dir, rec.n) > 0.0f;
                         } else {
@@ -1566,8 +1573,9 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
                     const rt_material m = sc.materials[rec.mat];
                     if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
                         const f3 emitted = (TEX > 0 && m.tex >= 0) ? texture_value<TEX>(sc, m.tex, rec.u, rec.v, rec.p) : ld3(m.albedo);
-                        const f3 add = thr * emitted;                       // main.cu:71; scatter() is false
-                        SF(F_RAD, slot) += add.x; SF(F_RAD + 1, slot) += add.y; SF(F_RAD + 2, slot) += add.z;
+                        // main.cu:71; scatter() is false
+                        SF(F_RAD, slot) = fmaf(thr.x, emitted.x, SF(F_RAD, slot)); SF(F_RAD + 1, slot) = fmaf(thr.y, emitted.y, SF(F_RAD + 1, slot));
+                        SF(F_RAD + 2, slot) = fmaf(thr.z, emitted.z, SF(F_RAD + 2, slot));
                         dest = 2;
                     } else {
                         rt_xorwow g;
@@ -1582,7 +1590,7 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
                             const f3 rs = random_in_unit_sphere(g);         // shared by lambertian / metal / isotropic
                             if (m.kind == RT_MAT_METAL) {
                                 const f3 reflected = reflect(unit_vector(r.d), rec.n);
-                                dir = reflected + m.fuzz * rs;
+                                dir = fma3(m.fuzz, rs, reflected);
                                 attenuation = ld3(m.albedo);
                                 go_on = dot(dir, rec.n) > 0.0f;
                             } else {
@@ -1644,7 +1652,7 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
                             Ray mr; mr.o = mk3(0, 0, 0); mr.tm = 0.f;
                             mr.d = mk3(SF(F_DX, slot), SF(F_DY, slot), SF(F_DZ, slot));
                             const f3 thr = mk3(SF(F_THR, slot), SF(F_THR + 1, slot), SF(F_THR + 2, slot));
-                            rad = rad + thr * miss_color(fp, mr);                                 // radiance += throughput * bg
+                            rad = fma3(thr, miss_color(fp, mr), rad);                                 // radiance += throughput * bg
                         }
                         col = mk3(SF(F_COL, slot) + rad.x, SF(F_COL + 1, slot) + rad.y, SF(F_COL + 2, slot) + rad.z);   // col += color(...), main.cu:124
                         ++sample;

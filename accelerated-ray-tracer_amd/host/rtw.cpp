@@ -88,8 +88,8 @@ rotate_y::rotate_y(hittable* p, float angle_degrees) : obj(p) {
                 const float x = i ? b.maximum.x() : b.minimum.x();
                 const float y = j ? b.maximum.y() : b.minimum.y();
                 const float z = k ? b.maximum.z() : b.minimum.z();
-                const float rx = cos_t * x + sin_t * z;
-                const float rz = -sin_t * x + cos_t * z;
+                const float rx = fmaf(cos_t, x, sin_t * z);
+                const float rz = fmaf(-sin_t, x, cos_t * z);
                 lo = vec3(fminf(lo.x(), rx), fminf(lo.y(), y), fminf(lo.z(), rz));
                 hi = vec3(fmaxf(hi.x(), rx), fmaxf(hi.y(), y), fmaxf(hi.z(), rz));
             }
@@ -142,10 +142,15 @@ void camera::init(vec3 lookfrom, vec3 lookat, vec3 vup, float vfov, float aspect
     const float half_height = tanf(theta * 0.5f);
     const float half_width = aspect * half_height;
     origin = lookfrom;
-    w = unit_vector(lookfrom - lookat);
-    u = unit_vector(cross(vup, w));
-    v = cross(w, u);
-    lower_left_corner = origin - half_width * focus_dist * u - half_height * focus_dist * v - focus_dist * w;
+    // lookfrom, lookat, vup, vfov and focus_dist are compile-time constants in every reference scene kernel, so the
+    // basis and the terms built only from them are folded per operation (no contraction); aspect (nx/ny) is a kernel
+    // argument, so the half_width term is a run-time product contracted into the subtraction.
+    const vec3 dw = lookfrom - lookat;
+    w = dw / dw.length_folded();
+    const vec3 du = cross_folded(vup, w);
+    u = du / du.length_folded();
+    v = cross_folded(w, u);
+    lower_left_corner = fma3(-(half_width * focus_dist), u, origin) - half_height * focus_dist * v - focus_dist * w;
     horizontal = 2.0f * half_width * focus_dist * u;
     vertical = 2.0f * half_height * focus_dist * v;
 }

@@ -38,8 +38,12 @@ struct vec3 {
     float operator[](int i) const { return e[i]; }
     float& operator[](int i) { return e[i]; }
     vec3 operator-() const { return vec3(-e[0], -e[1], -e[2]); }
-    float length() const { return sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]); }
-    float squared_length() const { return e[0] * e[0] + e[1] * e[1] + e[2] * e[2]; }
+    // Contracted the way nvcc's default -fmad=true contracts the reference's device code (DESIGN.md "numerical
+    // contract"): m0 + m1 + m2 = fma(m2, fma(m0, m1)).  The *_folded forms are the uncontracted per-operation values
+    // a compiler's constant folder produces; the reference's camera arguments are compile-time constants.
+    float length() const { return sqrtf(fmaf(e[2], e[2], fmaf(e[0], e[0], e[1] * e[1]))); }
+    float squared_length() const { return fmaf(e[2], e[2], fmaf(e[0], e[0], e[1] * e[1])); }
+    float length_folded() const { return sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]); }
 };
 inline vec3 operator+(const vec3& a, const vec3& b) { return vec3(a.e[0] + b.e[0], a.e[1] + b.e[1], a.e[2] + b.e[2]); }
 inline vec3 operator-(const vec3& a, const vec3& b) { return vec3(a.e[0] - b.e[0], a.e[1] - b.e[1], a.e[2] - b.e[2]); }
@@ -47,10 +51,14 @@ inline vec3 operator*(const vec3& a, const vec3& b) { return vec3(a.e[0] * b.e[0
 inline vec3 operator*(float t, const vec3& v) { return vec3(t * v.e[0], t * v.e[1], t * v.e[2]); }
 inline vec3 operator*(const vec3& v, float t) { return vec3(t * v.e[0], t * v.e[1], t * v.e[2]); }
 inline vec3 operator/(const vec3& v, float t) { return vec3(v.e[0] / t, v.e[1] / t, v.e[2] / t); }
-inline float dot(const vec3& a, const vec3& b) { return a.e[0] * b.e[0] + a.e[1] * b.e[1] + a.e[2] * b.e[2]; }
+inline float dot(const vec3& a, const vec3& b) { return fmaf(a.e[2], b.e[2], fmaf(a.e[0], b.e[0], a.e[1] * b.e[1])); }
 inline vec3 cross(const vec3& a, const vec3& b) {
+    return vec3(fmaf(a.e[1], b.e[2], -(a.e[2] * b.e[1])), -fmaf(a.e[0], b.e[2], -(a.e[2] * b.e[0])), fmaf(a.e[0], b.e[1], -(a.e[1] * b.e[0])));
+}
+inline vec3 cross_folded(const vec3& a, const vec3& b) {
     return vec3(a.e[1] * b.e[2] - a.e[2] * b.e[1], -(a.e[0] * b.e[2] - a.e[2] * b.e[0]), a.e[0] * b.e[1] - a.e[1] * b.e[0]);
 }
+inline vec3 fma3(float t, const vec3& v, const vec3& a) { return vec3(fmaf(t, v.e[0], a.e[0]), fmaf(t, v.e[1], a.e[1]), fmaf(t, v.e[2], a.e[2])); }   // a + t*v
 inline vec3 unit_vector(const vec3& v) { return v / v.length(); }
 
 // ------------------------------------------------------------------ aabb

@@ -66,8 +66,8 @@ void bouncing_spheres(built_scene& sc) {
     for (int a = -11; a < 11; ++a) {
         for (int b = -11; b < 11; ++b) {
             const float pick = rnd();
-            const float px = a + 0.9f * rnd();
-            const float pz = b + 0.9f * rnd();
+            const float px = fmaf(0.9f, rnd(), (float)a);   // a + 0.9f*RND, contracted
+            const float pz = fmaf(0.9f, rnd(), (float)b);
             const vec3 at(px, 0.2f, pz);
             if (pick < 0.8f) {
                 const float vy = 0.5f * rnd();
@@ -95,7 +95,7 @@ void bouncing_spheres(built_scene& sc) {
 
     const vec3 eye(13.0f, 2.0f, 3.0f), target(0.0f, 0.0f, 0.0f);
     finish(sc, objs, new camera(eye, target, vec3(0.0f, 1.0f, 0.0f), 30.0f, aspect_of(sc.nx, sc.ny), 0.1f,
-                                (eye - target).length(), 0.0, 1.0));
+                                (eye - target).length_folded(), 0.0, 1.0));
     sc.ppm_double_scale = true;
 }
 
@@ -180,7 +180,7 @@ void quads_scene(built_scene& sc) {
 
 camera* cornell_camera(const built_scene& sc) {
     const vec3 eye(278, 278, -800), target(278, 278, 0);
-    return new camera(eye, target, vec3(0, 1, 0), 40.0f, aspect_of(sc.nx, sc.ny), 0.0f, (eye - target).length(), 0.0, 1.0);
+    return new camera(eye, target, vec3(0, 1, 0), 40.0f, aspect_of(sc.nx, sc.ny), 0.0f, (eye - target).length_folded(), 0.0, 1.0);
 }
 
 // ---- main.cu:402-450 + 1072-1127 ----
@@ -257,11 +257,11 @@ void final_scene(built_scene& sc) {
     const float ct = cosf(turn), st = sinf(turn);
     for (int j = 0; j < 1000; ++j) {
         const vec3 q = random_in_unit_cube(j) * 165.0f;
-        const vec3 turned(ct * q.x() + st * q.z(), q.y(), -st * q.x() + ct * q.z());   // rotate_y_deg, main.cu:491-496
+        const vec3 turned(fmaf(ct, q.x(), st * q.z()), q.y(), fmaf(-st, q.x(), ct * q.z()));   // rotate_y_deg, main.cu:491-496
         objs.push_back(new sphere(turned + vec3(-100, 270, 395), 10.0f, white));
     }
     const vec3 eye(478, 278, -600), target(278, 278, 0);
-    finish(sc, objs, new camera(eye, target, vec3(0, 1, 0), 40.0f, aspect_of(sc.nx, sc.ny), 0.0f, (eye - target).length(), 0.0, 1.0));
+    finish(sc, objs, new camera(eye, target, vec3(0, 1, 0), 40.0f, aspect_of(sc.nx, sc.ny), 0.0f, (eye - target).length_folded(), 0.0, 1.0));
 }
 
 // ---- main.cu:360-400 + 995-1070 ----
@@ -276,7 +276,7 @@ void simple_light(built_scene& sc) {
     objs.push_back(new sphere(vec3(0, 7, 0), 2.f, new diffuse_light(vec3(4, 4, 4))));
     objs.push_back(new quad(vec3(3, 1, -2), vec3(2, 0, 0), vec3(0, 2, 0), new diffuse_light(vec3(4, 4, 4))));
     const vec3 eye(26, 3, 6), target(0, 2, 0);
-    finish(sc, objs, new camera(eye, target, vec3(0, 1, 0), 20.0f, aspect_of(sc.nx, sc.ny), 0.0f, (eye - target).length(), 0.0, 1.0));
+    finish(sc, objs, new camera(eye, target, vec3(0, 1, 0), 20.0f, aspect_of(sc.nx, sc.ny), 0.0f, (eye - target).length_folded(), 0.0, 1.0));
 }
 
 // ---- main.cu:564-635 + 1239-1305: the scene the reference's main() actually renders (case 10) ----
@@ -308,11 +308,11 @@ void original_scene(built_scene& sc) {
     const float ct = cosf(turn), st = sinf(turn);
     for (int j = 0; j < 1000; ++j) {
         const vec3 q = random_in_unit_cube(j) * 165.0f;
-        const vec3 turned(ct * q.x() + st * q.z(), q.y(), -st * q.x() + ct * q.z());
+        const vec3 turned(fmaf(ct, q.x(), st * q.z()), q.y(), fmaf(-st, q.x(), ct * q.z()));
         objs.push_back(new sphere(turned + vec3(-100, 270, 395), 10.0f, white));
     }
     const vec3 eye(478, 278, -600), target(278, 278, 0);
-    finish(sc, objs, new camera(eye, target, vec3(0, 1, 0), 40.0f, aspect_of(sc.nx, sc.ny), 0.0f, (eye - target).length(), 0.0, 1.0));
+    finish(sc, objs, new camera(eye, target, vec3(0, 1, 0), 40.0f, aspect_of(sc.nx, sc.ny), 0.0f, (eye - target).length_folded(), 0.0, 1.0));
     sc.background = vec3(0.043f, 0.030f, 0.094f);      // main.cu:1276
 }
 

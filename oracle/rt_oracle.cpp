@@ -70,12 +70,17 @@ inline V3 vmul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }      
 inline V3 vscale(float t, V3 v) { return v3(t * v.x, t * v.y, t * v.z); }           // vec3.cuh:77,87
 inline V3 vdivs(V3 v, float t) { return v3(v.x / t, v.y / t, v.z / t); }            // vec3.cuh:82
 inline V3 vneg(V3 v) { return v3(-v.x, -v.y, -v.z); }
-inline float vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }         // vec3.cuh:92
+// contracted forms (see "Floating-point contract" in the header): m0 + m1 + m2 = fma(m2, fma(m0, m1))
+inline float vdot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.x, b.x, a.y * b.y)); } // vec3.cuh:92
 inline V3 vcross(V3 a, V3 b) {                                                       // vec3.cuh:97
-    return v3(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x);
+    return v3(fmaf(a.y, b.z, -(a.z * b.y)), -fmaf(a.x, b.z, -(a.z * b.x)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
-inline float vlen(V3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }         // vec3.cuh:32
-inline float vsqlen(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }              // vec3.cuh:33
+inline float vlen(V3 v) { return sqrtf(fmaf(v.z, v.z, fmaf(v.x, v.x, v.y * v.y))); } // vec3.cuh:32
+inline float vsqlen(V3 v) { return fmaf(v.z, v.z, fmaf(v.x, v.x, v.y * v.y)); }      // vec3.cuh:33
+inline float vlen_folded(V3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }   // constant-folded (uncontracted) forms
+inline V3 vcross_folded(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x); }
+inline V3 vfma(float t, V3 v, V3 a) { return v3(fmaf(t, v.x, a.x), fmaf(t, v.y, a.y), fmaf(t, v.z, a.z)); }      // a + t*v
+inline V3 vfnma(float t, V3 v, V3 a) { return v3(fmaf(-t, v.x, a.x), fmaf(-t, v.y, a.y), fmaf(-t, v.z, a.z)); }  // a - t*v
 inline V3 vunit(V3 v) { return vdivs(v, vlen(v)); }                                  // vec3.cuh:155
 // operator/=(float): reciprocal formed in double, rounded once (vec3.cuh:145-153)
 inline V3 vdiveq(V3 v, float t) { float k = (float)(1.0 / (double)t); return v3(v.x * k, v.y * k, v.z * k); }
@@ -93,7 +98,7 @@ const float PI_F = 3.141592654f;  // CUDART_PI_F
 // ---------------------------------------------------------------- ray
 // ray.cuh:5-21.  Time is a double; point_at narrows t to float before t*B.
 struct Ray { V3 o, d; double tm; };
-inline V3 ray_at(const Ray& r, double t) { float tf = (float)t; return vadd(r.o, vscale(tf, r.d)); }
+inline V3 ray_at(const Ray& r, double t) { float tf = (float)t; return vfma(tf, r.d, r.o); }   // A + t*B, one FMA per component
 
 // ---------------------------------------------------------------- XORWOW
 // cuRAND XORWOW, subsequence 0, offset 0 (call sites main.cu:92,104,
@@ -173,7 +178,7 @@ inline uint32_t wanghash(uint32_t x) {
 inline uint32_t mix3(int x, int y, int z) {
     return (uint32_t)x * 73856093u ^ (uint32_t)y * 19349663u ^ (uint32_t)z * 83492791u;
 }
-inline float u2m11(uint32_t h) { return (float)((h >> 8) & 0x00FFFFFFu) * (1.0f / 8388607.5f) - 1.0f; }
+inline float u2m11(uint32_t h) { return fmaf((float)((h >> 8) & 0x00FFFFFFu), (1.0f / 8388607.5f), -1.0f); }
 inline V3 perlin_grad(int xi, int yi, int zi) {
     uint32_t h = wanghash(mix3(xi, yi, zi));
     float a = u2m11(h);
@@ -194,14 +199,14 @@ inline float perlin_noise(V3 p) {
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int cc = 0; cc < 2; ++cc) {
         V3 weight = v3(u - (float)a, v - (float)b, w - (float)cc);
         float s = (a ? uu : (1.0f - uu)) * (b ? vv : (1.0f - vv)) * (cc ? ww : (1.0f - ww));
-        accum += s * vdot(c[a][b][cc], weight);
+        accum = fmaf(s, vdot(c[a][b][cc], weight), accum);
     }
     return accum;
 }
 inline float perlin_turb(V3 p, int depth) {                                          // perlin.cuh:72-82
     float accum = 0.0f; V3 temp = p; float weight = 1.0f;
     for (int i = 0; i < depth; ++i) {
-        accum += weight * perlin_noise(temp);
+        accum = fmaf(weight, perlin_noise(temp), accum);
         weight *= 0.5f;
         temp = v3(temp.x * 2.0f, temp.y * 2.0f, temp.z * 2.0f);
     }
@@ -244,16 +249,16 @@ V3 tex_value(const Tex* t, float u, float v, V3 p) {
     case TEX_NOODLE: {                                                              // texture.cuh:94-100
         float uu = vdot(p, t->dir);
         float wig = perlin_turb(vscale(t->f, p), t->octaves);
-        float stripes = fabsf(cr_sinf(t->k * uu + t->A * wig));
+        float stripes = fabsf(cr_sinf(fmaf(t->k, uu, t->A * wig)));
         float q = clamp01((stripes - 0.75f) / (0.98f - 0.75f));                    // smoothstep, texture.cuh:78-82
         float w = q * q * (3.0f - 2.0f * q);
-        return vadd(vscale(1.f - w, t->cG), vscale(w, t->cN));
+        return vfma(1.f - w, t->cG, vscale(w, t->cN));
     }
     case TEX_FELT: {                                                                // texture.cuh:124-147
         float m = perlin_noise(vscale(t->m_scale, p));
-        float phase = p.x * t->f_scale + 2.0f * perlin_turb(vscale(0.5f, p), 2);
+        float phase = fmaf(p.x, t->f_scale, 2.0f * perlin_turb(vscale(0.5f, p), 2));
         float fibers = 0.5f * (1.0f + cr_sinf(phase));
-        float gain = 1.0f + t->m_amt * (m - 0.5f) + t->f_amt * (fibers - 0.5f);
+        float gain = fmaf(t->f_amt, fibers - 0.5f, fmaf(t->m_amt, m - 0.5f, 1.0f));
         gain = fminf(fmaxf(gain, 0.7f), 1.2f);
         return vscale(gain, t->color);
     }
@@ -263,7 +268,7 @@ V3 tex_value(const Tex* t, float u, float v, V3 p) {
         return tex_value(t->base, uu, vv, p);
     }
     case TEX_NOISE: {                                                               // texture.cuh:67-72
-        float s = cr_sinf(t->scale * p.z + 10.0f * perlin_turb(p, 7));
+        float s = cr_sinf(fmaf(t->scale, p.z, 10.0f * perlin_turb(p, 7)));
         float tt = 0.5f * (1.0f + s);
         return v3(tt, tt, tt);
     }
@@ -293,13 +298,14 @@ inline V3 random_in_unit_sphere(Rng& g) {                                       
         if (vsqlen(p) < 1.0f) return p;
     }
 }
-inline V3 reflect(V3 v, V3 n) { return vsub(v, vscale(2.0f * vdot(v, n), n)); }      // material.cuh:20-23
+inline V3 reflect(V3 v, V3 n) { return vfnma(2.0f * vdot(v, n), n, v); }      // material.cuh:20-23
 inline bool refract(V3 v, V3 n, float ni_over_nt, V3& out) {                        // material.cuh:26-36
     V3 uv = vunit(v);
     float dt = vdot(uv, n);
-    float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+    float disc = fmaf(-(ni_over_nt * ni_over_nt), fmaf(-dt, dt, 1.0f), 1.0f);
     if (disc > 0.0f) {
-        out = vsub(vscale(ni_over_nt, vsub(uv, vscale(dt, n))), vscale(sqrtf(disc), n));
+        const V3 a = vfnma(dt, n, uv); const float sq = sqrtf(disc);                 // ni*(uv - n*dt) - n*sqrt(disc)
+        out = v3(fmaf(-sq, n.x, ni_over_nt * a.x), fmaf(-sq, n.y, ni_over_nt * a.y), fmaf(-sq, n.z, ni_over_nt * a.z));
         return true;
     }
     return false;
@@ -307,7 +313,7 @@ inline bool refract(V3 v, V3 n, float ni_over_nt, V3& out) {                    
 inline float schlick(float cosine, float ref_idx) {                                 // material.cuh:38-43
     float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
     r0 = r0 * r0;
-    return r0 + (1.0f - r0) * cr_powf(1.0f - cosine, 5.0f);
+    return fmaf(1.0f - r0, cr_powf(1.0f - cosine, 5.0f), r0);
 }
 V3 mat_emitted(const Mat* m, float u, float v, V3 p) {                              // material.cuh:49-52,169-172
     if (m->kind != MAT_LIGHT) return v3(0.f, 0.f, 0.f);
@@ -324,7 +330,7 @@ bool mat_scatter(const Mat* m, const Ray& in, const Hit& rec, V3& atten, Ray& ou
     case MAT_METAL: {                                                               // material.cuh:99-109
         V3 refl = reflect(vunit(in.d), rec.n);
         V3 rs = random_in_unit_sphere(g);
-        out.o = rec.p; out.d = vadd(refl, vscale(m->fuzz, rs)); out.tm = in.tm;
+        out.o = rec.p; out.d = vfma(m->fuzz, rs, refl); out.tm = in.tm;
         atten = m->albedo;
         return vdot(out.d, rec.n) > 0.0f;
     }
@@ -336,7 +342,7 @@ bool mat_scatter(const Mat* m, const Ray& in, const Hit& rec, V3& atten, Ray& ou
             outward = vneg(rec.n);
             ni_over_nt = m->ior;
             cosine = vdot(in.d, rec.n) / vlen(in.d);
-            cosine = sqrtf(fmaxf(0.0f, 1.0f - m->ior * m->ior * (1.0f - cosine * cosine)));
+            cosine = sqrtf(fmaxf(0.0f, fmaf(-(m->ior * m->ior), fmaf(-cosine, cosine, 1.0f), 1.0f)));
         } else {
             outward = rec.n;
             ni_over_nt = 1.0f / m->ior;
@@ -394,8 +400,8 @@ bool sphere_hit(const Obj* s, const Ray& r, float tmin, float tmax, Hit& rec) { 
     V3 oc = vsub(r.o, cc);
     float a = vdot(r.d, r.d);
     float b = vdot(oc, r.d);
-    float c = vdot(oc, oc) - s->radius * s->radius;
-    float disc = b * b - a * c;
+    float c = fmaf(-s->radius, s->radius, vdot(oc, oc));
+    float disc = fmaf(b, b, -(a * c));
     if (disc <= 0.0f) return false;
     float sq = sqrtf(disc);
     float t = (-b - sq) / a;
@@ -450,16 +456,16 @@ bool translate_hit(const Obj* t, const Ray& r, float tmin, float tmax, Hit& rec)
 bool roty_hit(const Obj* ro, const Ray& r, float tmin, float tmax, Hit& rec) {       // hittable.cuh:118-145
     if (g_cnt) g_cnt->inst_calls++;
     const float c = ro->cos_t, s = ro->sin_t;
-    const float ox = c * r.o.x - s * r.o.z;
-    const float oz = s * r.o.x + c * r.o.z;
-    const float dx = c * r.d.x - s * r.d.z;
-    const float dz = s * r.d.x + c * r.d.z;
+    const float ox = fmaf(c, r.o.x, -(s * r.o.z));
+    const float oz = fmaf(s, r.o.x, c * r.o.z);
+    const float dx = fmaf(c, r.d.x, -(s * r.d.z));
+    const float dz = fmaf(s, r.d.x, c * r.d.z);
     Ray rr; rr.o = v3(ox, r.o.y, oz); rr.d = v3(dx, r.d.y, dz); rr.tm = r.tm;
     if (!obj_hit(ro->child, rr, tmin, tmax, rec)) return false;
-    const float px = c * rec.p.x + s * rec.p.z;
-    const float pz = -s * rec.p.x + c * rec.p.z;
-    const float nx = c * rec.n.x + s * rec.n.z;
-    const float nz = -s * rec.n.x + c * rec.n.z;
+    const float px = fmaf(c, rec.p.x, s * rec.p.z);
+    const float pz = fmaf(-s, rec.p.x, c * rec.p.z);
+    const float nx = fmaf(c, rec.n.x, s * rec.n.z);
+    const float nz = fmaf(-s, rec.n.x, c * rec.n.z);
     rec.p = v3(px, rec.p.y, pz);
     rec.n = vunit(v3(nx, rec.n.y, nz));
     if (vdot(rec.n, r.d) > 0.f) rec.n = vneg(rec.n);
@@ -534,13 +540,14 @@ Camera make_camera(V3 lookfrom, V3 lookat, V3 vup, float vfov, float aspect, flo
     float half_height = tanf(theta * 0.5f);
     float half_width = aspect * half_height;
     c.origin = lookfrom;
-    c.w = vunit(vsub(lookfrom, lookat));
-    c.u = vunit(vcross(vup, c.w));
-    c.v = vcross(c.w, c.u);
-    V3 a = vscale(half_width * focus_dist, c.u);
-    V3 b = vscale(half_height * focus_dist, c.v);
-    V3 cc = vscale(focus_dist, c.w);
-    c.llc = vsub(vsub(vsub(c.origin, a), b), cc);
+    // lookfrom, lookat, vup, vfov and focus_dist are compile-time constants in every reference scene kernel
+    // (main.cu:233-241 and the like), so the basis and the terms built only from them are what a constant folder
+    // produces: one rounding per written operation, no contraction.  aspect = nx/ny is a kernel argument, so the
+    // half_width term below is a run-time product and is contracted into the subtraction.
+    { V3 d = vsub(lookfrom, lookat); c.w = vdivs(d, vlen_folded(d)); }
+    { V3 d = vcross_folded(vup, c.w); c.u = vdivs(d, vlen_folded(d)); }
+    c.v = vcross_folded(c.w, c.u);
+    c.llc = vsub(vsub(vfnma(half_width * focus_dist, c.u, c.origin), vscale(half_height * focus_dist, c.v)), vscale(focus_dist, c.w));
     c.horizontal = vscale(2.0f * half_width * focus_dist, c.u);
     c.vertical = vscale(2.0f * half_height * focus_dist, c.v);
     return c;
@@ -556,11 +563,11 @@ inline V3 random_in_unit_disk(Rng& g) {                                         
 }
 Ray camera_get_ray(const Camera& c, float s, float t, Rng& g) {                      // camera.cuh:35-47
     V3 rd = vscale(c.lens_radius, random_in_unit_disk(g));
-    V3 offset = vadd(vscale(rd.x, c.u), vscale(rd.y, c.v));
-    double tm = c.time0 + (double)rng_uniform(g) * (c.time1 - c.time0);
+    V3 offset = vfma(rd.x, c.u, vscale(rd.y, c.v));
+    double tm = fma((double)rng_uniform(g), c.time1 - c.time0, c.time0);
     Ray r;
     r.o = vadd(c.origin, offset);
-    r.d = vsub(vsub(vadd(vadd(c.llc, vscale(s, c.horizontal)), vscale(t, c.vertical)), c.origin), offset);
+    r.d = vsub(vsub(vfma(t, c.vertical, vfma(s, c.horizontal, c.llc)), c.origin), offset);
     r.tm = tm;
     return r;
 }
@@ -658,8 +665,8 @@ struct Scene {
         V3 lo = v3(FLT_MAX, FLT_MAX, FLT_MAX), hi = v3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 2; ++k) {
             float x = i ? b.hi.x : b.lo.x, y = j ? b.hi.y : b.lo.y, z = k ? b.hi.z : b.lo.z;
-            float nx = o->cos_t * x + o->sin_t * z;
-            float nz = -o->sin_t * x + o->cos_t * z;
+            float nx = fmaf(o->cos_t, x, o->sin_t * z);
+            float nz = fmaf(-o->sin_t, x, o->cos_t * z);
             lo = v3(fminf(lo.x, nx), fminf(lo.y, y), fminf(lo.z, nz));
             hi = v3(fmaxf(hi.x, nx), fmaxf(hi.y, y), fmaxf(hi.z, nz));
         }
@@ -748,8 +755,8 @@ void scene_bouncing(Scene& S, int nx, int ny) {
     S.push(S.sphere(v3(0.0f, -1000.0f, -1.0f), 1000.0f, S.lambertian(checker)));
     for (int a = -11; a < 11; ++a) for (int b = -11; b < 11; ++b) {
         float choose = rng_uniform(g);
-        float cx = (float)a + 0.9f * rng_uniform(g);
-        float cz = (float)b + 0.9f * rng_uniform(g);
+        float cx = fmaf(0.9f, rng_uniform(g), (float)a);
+        float cz = fmaf(0.9f, rng_uniform(g), (float)b);
         V3 center = v3(cx, 0.2f, cz);
         if (choose < 0.8f) {
             float vy = 0.5f * rng_uniform(g);
@@ -775,7 +782,7 @@ void scene_bouncing(Scene& S, int nx, int ny) {
     S.push(S.sphere(v3(4.0f, 1.0f, 0.0f), 1.0f, S.metal(v3(0.7f, 0.6f, 0.5f), 0.0f)));
     S.finish();
     V3 from = v3(13.0f, 2.0f, 3.0f), at = v3(0, 0, 0);
-    S.cam = make_camera(from, at, v3(0, 1, 0), 30.0f, (float)nx / (float)ny, 0.1f, vlen(vsub(from, at)), 0.0, 1.0);
+    S.cam = make_camera(from, at, v3(0, 1, 0), 30.0f, (float)nx / (float)ny, 0.1f, vlen_folded(vsub(from, at)), 0.0, 1.0);
     S.gradient = 0; S.def_nx = 1200; S.def_ny = 600; S.def_ns = 10000;
 }
 
@@ -834,7 +841,7 @@ void scene_cornell(Scene& S, int nx, int ny) {
     S.push(S.sphere(v3(278.f, 335.f, 150.f), -59.0f, glass));
     S.finish();
     V3 from = v3(278, 278, -800), at = v3(278, 278, 0);
-    S.cam = make_camera(from, at, v3(0, 1, 0), 40.0f, (float)nx / (float)ny, 0.0f, vlen(vsub(from, at)), 0.0, 1.0);
+    S.cam = make_camera(from, at, v3(0, 1, 0), 40.0f, (float)nx / (float)ny, 0.0f, vlen_folded(vsub(from, at)), 0.0, 1.0);
     S.gradient = 0; S.def_nx = 600; S.def_ny = 600; S.def_ns = 10000;
 }
 
@@ -858,7 +865,7 @@ void scene_cornell_smoke(Scene& S, int nx, int ny) {
     S.push(S.medium(b2, 0.01f, v3(1, 1, 1)));
     S.finish();
     V3 from = v3(278, 278, -800), at = v3(278, 278, 0);
-    S.cam = make_camera(from, at, v3(0, 1, 0), 40.0f, (float)nx / (float)ny, 0.0f, vlen(vsub(from, at)), 0.0, 1.0);
+    S.cam = make_camera(from, at, v3(0, 1, 0), 40.0f, (float)nx / (float)ny, 0.0f, vlen_folded(vsub(from, at)), 0.0, 1.0);
     S.gradient = 0; S.def_nx = 600; S.def_ny = 600; S.def_ns = 1000;
 }
 
@@ -899,13 +906,13 @@ void scene_final(Scene& S, int nx, int ny) {
         V3 p = vscale(165.0f, cube_point(j));
         float r = 15.0f * 0.017453292519943295f;                                    // main.cu:489-496
         float c = cosf(r), s = sinf(r);
-        p = v3(c * p.x + s * p.z, p.y, -s * p.x + c * p.z);
+        p = v3(fmaf(c, p.x, s * p.z), p.y, fmaf(-s, p.x, c * p.z));
         p = vadd(p, v3(-100, 270, 395));
         S.push(S.sphere(p, 10.0f, white));
     }
     S.finish();
     V3 from = v3(478, 278, -600), at = v3(278, 278, 0);
-    S.cam = make_camera(from, at, v3(0, 1, 0), 40.0f, (float)nx / (float)ny, 0.0f, vlen(vsub(from, at)), 0.0, 1.0);
+    S.cam = make_camera(from, at, v3(0, 1, 0), 40.0f, (float)nx / (float)ny, 0.0f, vlen_folded(vsub(from, at)), 0.0, 1.0);
     S.gradient = 0; S.def_nx = 800; S.def_ny = 800; S.def_ns = 10000;
 }
 
@@ -958,7 +965,7 @@ void scene_simple_light(Scene& S, int nx, int ny) {
     S.push(S.quad(v3(3, 1, -2), v3(2, 0, 0), v3(0, 2, 0), S.light(v3(4, 4, 4))));
     S.finish();
     V3 from = v3(26, 3, 6), at = v3(0, 2, 0);
-    S.cam = make_camera(from, at, v3(0, 1, 0), 20.0f, (float)nx / (float)ny, 0.0f, vlen(vsub(from, at)), 0.0, 1.0);
+    S.cam = make_camera(from, at, v3(0, 1, 0), 20.0f, (float)nx / (float)ny, 0.0f, vlen_folded(vsub(from, at)), 0.0, 1.0);
     S.gradient = 0; S.def_nx = 1200; S.def_ny = 600; S.def_ns = 10000;
 }
 
@@ -988,13 +995,13 @@ void scene_original(Scene& S, int nx, int ny) {
         V3 p = vscale(165.0f, cube_point(j));
         float r = 15.0f * 0.017453292519943295f;
         float c = cosf(r), s = sinf(r);
-        p = v3(c * p.x + s * p.z, p.y, -s * p.x + c * p.z);
+        p = v3(fmaf(c, p.x, s * p.z), p.y, fmaf(-s, p.x, c * p.z));
         p = vadd(p, v3(-100, 270, 395));
         S.push(S.sphere(p, 10.0f, white));
     }
     S.finish();
     V3 from = v3(478, 278, -600), at = v3(278, 278, 0);
-    S.cam = make_camera(from, at, v3(0, 1, 0), 40.0f, (float)nx / (float)ny, 0.0f, vlen(vsub(from, at)), 0.0, 1.0);
+    S.cam = make_camera(from, at, v3(0, 1, 0), 40.0f, (float)nx / (float)ny, 0.0f, vlen_folded(vsub(from, at)), 0.0, 1.0);
     S.gradient = 0; S.background = v3(0.043f, 0.030f, 0.094f); S.def_nx = 800; S.def_ny = 800; S.def_ns = 10000;
 }
 
@@ -1016,12 +1023,13 @@ V3 path_color(const Scene& S, const Ray& r0, V3 background, bool gradient, Rng& 
             if (gradient) {
                 V3 ud = vunit(cur.d);
                 float t = 0.5f * (ud.y + 1.0f);
-                bg = vadd(vscale(1.0f - t, v3(1.0f, 1.0f, 1.0f)), vscale(t, v3(0.5f, 0.7f, 1.0f)));
+                bg = v3(fmaf(t, 0.5f, 1.0f - t), fmaf(t, 0.7f, 1.0f - t), (1.0f - t) + t);   // (1-t)*1 folds to (1-t), t*1 to t
             }
-            radiance = vadd(radiance, vmul(throughput, bg));
+            radiance = v3(fmaf(throughput.x, bg.x, radiance.x), fmaf(throughput.y, bg.y, radiance.y), fmaf(throughput.z, bg.z, radiance.z));
             break;
         }
-        radiance = vadd(radiance, vmul(throughput, mat_emitted(rec.mat, (float)rec.u, (float)rec.v, rec.p)));
+        const V3 em = mat_emitted(rec.mat, (float)rec.u, (float)rec.v, rec.p);
+        radiance = v3(fmaf(throughput.x, em.x, radiance.x), fmaf(throughput.y, em.y, radiance.y), fmaf(throughput.z, em.z, radiance.z));
         Ray scattered; V3 atten;
         if (!mat_scatter(rec.mat, cur, rec, atten, scattered, g)) break;
         throughput = vmul(throughput, atten);
