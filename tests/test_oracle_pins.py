@@ -52,7 +52,10 @@ def test_traversal_counters_match_survey(orc, name):
     sc = orc.OracleScene(name, p["nx"], p["ny"])
     _, c = sc.render(p["ns"])
     rays = c["rays"]
-    tol = 2e-3 if name == "final" else 6e-4   # the pins are printed to 3-4 significant digits
+    # The surveyor measured these on an uncontracted CPU build of the reference's device code; the oracle now contracts
+    # mul+add into FMA where the reference's real (nvcc) build does, which re-rolls individual paths, so the counters
+    # agree statistically (<= 1 %), not to the printed digit.  Pixel-level pins: tests/test_reference_images.py.
+    tol = 1e-2
     assert abs(rays / c["samples"] - p["rays_per_sample"]) <= tol * p["rays_per_sample"] + 5e-3
     assert abs(c["box_tests"] / rays - p["box_tests_per_ray"]) <= tol * p["box_tests_per_ray"] + 5e-3
     prim = (c["sphere_tests"] + c["quad_tests"]) / rays
