@@ -23,11 +23,14 @@
 //     pixel still consumes its own random stream in the reference's order.
 //   * No MFMA: there is no dense contraction anywhere on this path.
 //
-// Built with -ffp-contract=off: every fp32 + - * / sqrt below is a single
-// IEEE operation in the reference's written order.  Transcendentals (powf in
-// gamma and Schlick, logf in the medium, __sinf in the noise texture, acos /
-// atan2 in sphere uv) are evaluated in double and rounded once, which gives
-// the correctly rounded binary32 value except with probability ~1e-8.
+// Numerical contract: the arithmetic of the reference's real
+// build.  nvcc's default -fmad=true contracts a*b+c into one FMA; those
+// contractions are written out below with fmaf() and the file is built with
+// -ffp-contract=off so the compiler neither adds nor removes one.  Every rule
+// was checked against the reference's own output images, six of which this
+// code reproduces pixel for pixel.  Transcendentals (powf in gamma and
+// Schlick, logf in the medium, __sinf in the noise texture, acos / atan2 in
+// sphere uv) are evaluated in double and rounded once.
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>

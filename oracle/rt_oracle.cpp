@@ -13,34 +13,38 @@
 // stand-in headers is not allowed).  What the reference does hold is output:
 // its README images (images/*.png) are lossless 8-bit copies of the PPM the
 // CUDA binary printed for nine scene functions of the current source at their
-// own nx, ny, ns and seeds.  This oracle is pinned against those at 8-bit
-// level (tests/test_reference_images.py, tests/golden/reference_image_pins.npz;
-// full-frame rates in profiles/r01_reference_image_match.txt): quads 99.997 %
-// of 720,000 pixels identical and the rest off by one level, checker / earth /
-// perlin / simple_light 97.7-99.6 % identical, the 10000-spp scenes identical
-// until a pixel's sample stream first diverges and noise-equivalent after.
+// own nx, ny, ns and seeds.  This oracle is pinned against those
+// (tests/test_reference_images.py, tests/golden/reference_image_pins.npz;
+// full frames in profiles/r01_reference_image_match.txt): it reproduces the
+// pinned rows of quads, checker, earth, perlin, simple_light (10000 spp) and
+// the headline random scene (10000 spp) pixel for pixel, Cornell 89 %, and the
+// two scenes dominated by constant_medium / __sinf to Monte-Carlo noise.
 // That pins the XORWOW stream (restated here from the published cuRAND
 // algorithm), per-pixel seeding, draw order, scene construction, BVH rules,
-// hit routines, materials, textures, camera, accumulation and gamma.
-// NOT pinned: fp32 bit-level parity with a CUDA build -- no fp32 output of the
-// reference exists, nvcc contracts a*b+c into FMA by default and CUDA's
-// transcendentals are not correctly rounded, so "parity unpinned" still
-// applies below the 8-bit level.  Further outside pins: the counters SURVEY.md
-// section 8 recorded from the reference's own code (scene structure, rays per
-// sample, box tests per ray) -- tests/golden/survey_pins.json,
-// tests/test_oracle_pins.py.
+// hit routines, materials, textures, camera, accumulation, gamma and the
+// contraction rules below against the CUDA binary itself.  No fp32 output of
+// the reference exists, so nothing is claimed below the 8-bit level.  Further
+// outside pins: the counters SURVEY.md section 8 recorded from the reference's
+// own code -- tests/golden/survey_pins.json, tests/test_oracle_pins.py.
 //
-// Floating-point contract of this oracle ("reference semantics"):
-//   * IEEE-754 binary32 for + - * / sqrt, no FMA contraction (build with
-//     -ffp-contract=off), operations in the reference's written order.
+// Floating-point contract of this oracle = the reference's real build (nvcc
+// defaults: IEEE div/sqrt, -fmad=true), every rule checked against the images:
+//   * IEEE-754 binary32 for + - * / sqrt.  Built with -ffp-contract=off; the
+//     FMA contractions nvcc performs are written out with fmaf(): a product
+//     whose only use is an add/sub is fused with it; of two products under one
+//     add/sub the first is fused (dot = fma(z,z', fma(x,x', y*y'))), except in
+//     refract's last line, where the second is.
+//   * The camera basis, dist_to_focus and the lower_left_corner terms built
+//     only from them are compile-time constants in the reference's scene
+//     kernels: folded one operation at a time, no contraction (*_folded).
 //   * Where the reference leaves argument evaluation order unspecified
 //     (material.cuh:15, camera.cuh:11-12, main.cu:188,193) draws are taken
 //     left to right.
 //   * Transcendentals (powf, logf, __sinf, acos, atan2) are evaluated as the
 //     correctly rounded binary32 value (double libm, then one rounding):
-//     CUDA's device versions are only specified to within a few ulp of that,
-//     so it is the canonical representative.  Host-side scene construction
-//     (tanf, sinf, cosf) uses libm float functions.
+//     CUDA's device versions are only specified to within a few ulp of that.
+//     Host-side scene construction (tanf, sinf, cosf) uses libm float
+//     functions.
 //
 // Structure is deliberately unlike the product: a pointer-linked object tree
 // walked recursively, the way the reference does it, so that the product's
