@@ -27,7 +27,7 @@
 // build.  nvcc's default -fmad=true contracts a*b+c into one FMA; those
 // contractions are written out below with fmaf() and the file is built with
 // -ffp-contract=off so the compiler neither adds nor removes one.  Every rule
-// was checked against the reference's own output images, six of which this
+// was checked against the reference's own output images, seven of which this
 // code reproduces pixel for pixel.  Transcendentals (powf in gamma and
 // Schlick, logf in the medium, __sinf in the noise texture, acos / atan2 in
 // sphere uv) are evaluated in double and rounded once.
@@ -298,9 +298,9 @@ DEV HitRec resolve_hit(const SceneView& sc, const Ray& r, const HitInfo& h) {
         if (in.flags & RT_INST_ROTATE_Y) {                  // hittable.cuh:129-142
             const float c = in.cos_t, s = in.sin_t;
             const float px = fmaf(c, rec.p.x, s * rec.p.z);
-            const float pz = fmaf(-s, rec.p.x, c * rec.p.z);
+            const float pz = fmaf(c, rec.p.z, -(s * rec.p.x));   // -s*x + c*z = c*z - s*x: the c*z product is the fused one
             const float nx = fmaf(c, rec.n.x, s * rec.n.z);
-            const float nz = fmaf(-s, rec.n.x, c * rec.n.z);
+            const float nz = fmaf(c, rec.n.z, -(s * rec.n.x));
             rec.p = mk3(px, rec.p.y, pz);
             rec.n = unit_vector(mk3(nx, rec.n.y, nz));
             // "faces against the original ray": rotate_y::hit sees the translated ray

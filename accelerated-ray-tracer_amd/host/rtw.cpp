@@ -89,7 +89,7 @@ rotate_y::rotate_y(hittable* p, float angle_degrees) : obj(p) {
                 const float y = j ? b.maximum.y() : b.minimum.y();
                 const float z = k ? b.maximum.z() : b.minimum.z();
                 const float rx = fmaf(cos_t, x, sin_t * z);
-                const float rz = fmaf(-sin_t, x, cos_t * z);
+                const float rz = fmaf(cos_t, z, -(sin_t * x));   // -s*x + c*z = c*z - s*x: the c*z product is the fused one
                 lo = vec3(fminf(lo.x(), rx), fminf(lo.y(), y), fminf(lo.z(), rz));
                 hi = vec3(fmaxf(hi.x(), rx), fmaxf(hi.y(), y), fmaxf(hi.z(), rz));
             }

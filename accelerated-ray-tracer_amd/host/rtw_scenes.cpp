@@ -257,7 +257,7 @@ void final_scene(built_scene& sc) {
     const float ct = cosf(turn), st = sinf(turn);
     for (int j = 0; j < 1000; ++j) {
         const vec3 q = random_in_unit_cube(j) * 165.0f;
-        const vec3 turned(fmaf(ct, q.x(), st * q.z()), q.y(), fmaf(-st, q.x(), ct * q.z()));   // rotate_y_deg, main.cu:491-496
+        const vec3 turned(fmaf(ct, q.x(), st * q.z()), q.y(), fmaf(ct, q.z(), -(st * q.x())));   // rotate_y_deg, main.cu:491-496
         objs.push_back(new sphere(turned + vec3(-100, 270, 395), 10.0f, white));
     }
     const vec3 eye(478, 278, -600), target(278, 278, 0);
@@ -308,7 +308,7 @@ void original_scene(built_scene& sc) {
     const float ct = cosf(turn), st = sinf(turn);
     for (int j = 0; j < 1000; ++j) {
         const vec3 q = random_in_unit_cube(j) * 165.0f;
-        const vec3 turned(fmaf(ct, q.x(), st * q.z()), q.y(), fmaf(-st, q.x(), ct * q.z()));
+        const vec3 turned(fmaf(ct, q.x(), st * q.z()), q.y(), fmaf(ct, q.z(), -(st * q.x())));
         objs.push_back(new sphere(turned + vec3(-100, 270, 395), 10.0f, white));
     }
     const vec3 eye(478, 278, -600), target(278, 278, 0);

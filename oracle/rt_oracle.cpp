@@ -16,9 +16,9 @@
 // own nx, ny, ns and seeds.  This oracle is pinned against those
 // (tests/test_reference_images.py, tests/golden/reference_image_pins.npz;
 // full frames in profiles/r01_reference_image_match.txt): it reproduces the
-// pinned rows of quads, checker, earth, perlin, simple_light (10000 spp) and
-// the headline random scene (10000 spp) pixel for pixel, Cornell 89 %, and the
-// two scenes dominated by constant_medium / __sinf to Monte-Carlo noise.
+// pinned rows of quads, checker, earth, perlin, simple_light, Cornell and the
+// headline random scene (the last three at 10000 spp) pixel for pixel, and the
+// two scenes whose rays all pass a constant_medium to Monte-Carlo noise.
 // That pins the XORWOW stream (restated here from the published cuRAND
 // algorithm), per-pixel seeding, draw order, scene construction, BVH rules,
 // hit routines, materials, textures, camera, accumulation, gamma and the
@@ -32,8 +32,8 @@
 //   * IEEE-754 binary32 for + - * / sqrt.  Built with -ffp-contract=off; the
 //     FMA contractions nvcc performs are written out with fmaf(): a product
 //     whose only use is an add/sub is fused with it; of two products under one
-//     add/sub the first is fused (dot = fma(z,z', fma(x,x', y*y'))), except in
-//     refract's last line, where the second is.
+//     add/sub the first is fused (dot = fma(z,z', fma(x,x', y*y'))); -a*b + c*d
+//     is c*d - a*b; refract's last line fuses its second product.
 //   * The camera basis, dist_to_focus and the lower_left_corner terms built
 //     only from them are compile-time constants in the reference's scene
 //     kernels: folded one operation at a time, no contraction (*_folded).
@@ -467,9 +467,9 @@ bool roty_hit(const Obj* ro, const Ray& r, float tmin, float tmax, Hit& rec) {  
     Ray rr; rr.o = v3(ox, r.o.y, oz); rr.d = v3(dx, r.d.y, dz); rr.tm = r.tm;
     if (!obj_hit(ro->child, rr, tmin, tmax, rec)) return false;
     const float px = fmaf(c, rec.p.x, s * rec.p.z);
-    const float pz = fmaf(-s, rec.p.x, c * rec.p.z);
+    const float pz = fmaf(c, rec.p.z, -(s * rec.p.x));   // -s*x + c*z is c*z - s*x to the compiler: the c*z product is the fused one
     const float nx = fmaf(c, rec.n.x, s * rec.n.z);
-    const float nz = fmaf(-s, rec.n.x, c * rec.n.z);
+    const float nz = fmaf(c, rec.n.z, -(s * rec.n.x));
     rec.p = v3(px, rec.p.y, pz);
     rec.n = vunit(v3(nx, rec.n.y, nz));
     if (vdot(rec.n, r.d) > 0.f) rec.n = vneg(rec.n);
@@ -670,7 +670,7 @@ struct Scene {
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 2; ++k) {
             float x = i ? b.hi.x : b.lo.x, y = j ? b.hi.y : b.lo.y, z = k ? b.hi.z : b.lo.z;
             float nx = fmaf(o->cos_t, x, o->sin_t * z);
-            float nz = fmaf(-o->sin_t, x, o->cos_t * z);
+            float nz = fmaf(o->cos_t, z, -(o->sin_t * x));
             lo = v3(fminf(lo.x, nx), fminf(lo.y, y), fminf(lo.z, nz));
             hi = v3(fmaxf(hi.x, nx), fmaxf(hi.y, y), fmaxf(hi.z, nz));
         }
@@ -910,7 +910,7 @@ void scene_final(Scene& S, int nx, int ny) {
         V3 p = vscale(165.0f, cube_point(j));
         float r = 15.0f * 0.017453292519943295f;                                    // main.cu:489-496
         float c = cosf(r), s = sinf(r);
-        p = v3(fmaf(c, p.x, s * p.z), p.y, fmaf(-s, p.x, c * p.z));
+        p = v3(fmaf(c, p.x, s * p.z), p.y, fmaf(c, p.z, -(s * p.x)));
         p = vadd(p, v3(-100, 270, 395));
         S.push(S.sphere(p, 10.0f, white));
     }
@@ -999,7 +999,7 @@ void scene_original(Scene& S, int nx, int ny) {
         V3 p = vscale(165.0f, cube_point(j));
         float r = 15.0f * 0.017453292519943295f;
         float c = cosf(r), s = sinf(r);
-        p = v3(fmaf(c, p.x, s * p.z), p.y, fmaf(-s, p.x, c * p.z));
+        p = v3(fmaf(c, p.x, s * p.z), p.y, fmaf(c, p.z, -(s * p.x)));
         p = vadd(p, v3(-100, 270, 395));
         S.push(S.sphere(p, 10.0f, white));
     }
