@@ -203,17 +203,18 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "Mrays/s, 1200x800 random scene @ 500 spp (frame ms in ms_per_step)",
+            "metric": f"Mrays/s, {args.nx}x{args.ny} {'random' if args.scene in ('random_scene', 'bouncing') else args.scene} scene @ {args.ns} spp (frame ms in ms_per_step)",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene} (reference create_world_bouncing, src/main.cu:160) {args.nx}x{args.ny} @ {args.ns} spp, seed 1984+pixel",
+            "config": {"workload": (f"{args.scene} (reference create_world_bouncing, src/main.cu:160)" if args.scene in ("random_scene", "bouncing")
+                                    else f"{args.scene} (reference scene function of that name, src/main.cu)") + f" {args.nx}x{args.ny} @ {args.ns} spp, seed 1984+pixel",
                        "rays_per_frame": int(total_rays), "parallelism": f"rows{world}" if world > 1 else "single",
                        "tile_rows": TILE_ROWS if world > 1 else args.ny},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(kms, 3), "algorithmic_bytes_per_ray": bpr,
-                         "note": "scene is LDS-resident: algorithmic bytes are served by LDS, not HBM; kernel_ms is the device time of a step = the two launches of rt_render_staged_kernel (samples [0,32) and [32,ns)) of the cost-aware schedule (see DESIGN.md)"},
+                         "note": "scene is LDS-resident: algorithmic bytes are served by LDS, not HBM; kernel_ms is the device time of a step = the launches of the render kernel (two with the cost-aware schedule: samples [0,32) and [32,ns)), see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.scene, args.nx, args.ny, args.cpu_ns)
