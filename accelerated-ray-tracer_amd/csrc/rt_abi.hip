@@ -36,6 +36,7 @@ int opt_medium_threshold = 16;
 int opt_newpath_threshold = 24;
 int opt_sparse_stride = 8;      // lanes per pixel in sparse waves (64 / live lanes); 0 disables sparse waves
 int opt_split_samples = 32;      // samples per pixel rendered before pixels are ranked by measured cost
+int opt_presplit_samples = 8;    // a first, shorter look: samples [presplit, split) already run with tiers ranked on it (0 = off)
 int opt_tier1_factor_x10 = 70;   // tier 1 = heavy pixels costing >= this/10 x the mean
 int opt_tier1_pixels = 256;      // heavy pixels served with one live lane per wave
 int opt_heavy_factor_x10 = 40;   // a pixel is "heavy" when its prepass ray count is >= this/10 x the mean
@@ -250,6 +251,7 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "newpath_threshold") { if (value < 1 || value > 64) return invalid("newpath_threshold: 1..64"); opt_newpath_threshold = value; }
     else if (k == "sparse_stride") { if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return invalid("sparse_stride: 0, 2, 4, ... 64"); opt_sparse_stride = value; }
     else if (k == "heavy_factor_x10") { if (value < 10 || value > 1000) return invalid("heavy_factor_x10: 10..1000"); opt_heavy_factor_x10 = value; }
+    else if (k == "presplit_samples") { if (value < 0 || value > 4096) return invalid("presplit_samples: 0..4096"); opt_presplit_samples = value; }
     else if (k == "split_samples") { if (value < 1 || value > 4096) return invalid("split_samples: 1..4096"); opt_split_samples = value; }
     else if (k == "tier1_factor_x10") { if (value < 10 || value > 10000) return invalid("tier1_factor_x10: 10..10000"); opt_tier1_factor_x10 = value; }
     else if (k == "tier1_pixels") { if (value < 0 || value > 8192) return invalid("tier1_pixels: 0..8192"); opt_tier1_pixels = value; }
@@ -546,29 +548,25 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             HIPCHK(hipMalloc((void**)&s->d_heavy_pixels, (size_t)RT_HEAVY_CAP * sizeof(unsigned int)));
             s->tile_capacity = n_tiles; s->pixel_capacity = n_pixels;
         }
-        // ---- part 1: samples [0, S0)
-        HIPCHK(hipMemsetAsync(s->d_tile_cost, 0, n_tiles * sizeof(unsigned int), stream));
-        HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
-        rt_frame_params p1 = fp;
-        p1.sample_end = opt_split_samples; p1.state_out = s->d_state; p1.tile_cost = s->d_tile_cost;
-        rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, p1, grid, block, lds_bytes, stream);
-        HIPCHK(hipGetLastError());
-        s->h_tile_cost.resize(n_tiles); s->h_tile_order.resize(n_tiles);
-        unsigned long long rays1 = 0;
-        HIPCHK(hipMemcpyAsync(s->h_tile_cost.data(), s->d_tile_cost, n_tiles * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(&rays1, s->d_ray_counter, sizeof(rays1), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        split = true;
-        fp.state_in = s->d_state; fp.sample_begin = opt_split_samples;
-        // ---- tiles, dearest first
-        for (size_t t = 0; t < n_tiles; ++t) s->h_tile_order[t] = (unsigned int)t;
-        const unsigned int* cost = s->h_tile_cost.data();
-        std::stable_sort(s->h_tile_order.begin(), s->h_tile_order.end(), [cost](unsigned int a, unsigned int b) { return cost[a] > cost[b]; });
-        HIPCHK(hipMemcpyAsync(s->d_tile_order, s->h_tile_order.data(), n_tiles * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
-        fp.tile_order = s->d_tile_order;
-        // ---- heavy pixels
-        if (opt_sparse_stride > 0 && block.x >= 64) {
-            const double mean = (double)rays1 / (double)n_pixels;                    // rays per pixel in part 1
+        // One ranked part: reads what the pixels cost so far, orders the tiles, lists the heavy pixels and sizes the
+        // tiers for the launch described by `q` (which resumes every pixel from d_state).
+        auto rank_pixels = [&](rt_frame_params& q, dim3& grid_q) -> rt_status {
+            unsigned long long rays_so_far = 0;
+            s->h_tile_cost.resize(n_tiles); s->h_tile_order.resize(n_tiles);
+            HIPCHK(hipMemcpyAsync(s->h_tile_cost.data(), s->d_tile_cost, n_tiles * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(&rays_so_far, s->d_ray_counter, sizeof(rays_so_far), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            // ---- tiles, dearest first
+            for (size_t t = 0; t < n_tiles; ++t) s->h_tile_order[t] = (unsigned int)t;
+            const unsigned int* cost = s->h_tile_cost.data();
+            std::stable_sort(s->h_tile_order.begin(), s->h_tile_order.end(), [cost](unsigned int a, unsigned int b) { return cost[a] > cost[b]; });
+            HIPCHK(hipMemcpyAsync(s->d_tile_order, s->h_tile_order.data(), n_tiles * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
+            q.tile_order = s->d_tile_order;
+            q.heavy_pixels = nullptr; q.heavy_threshold = 0xFFFFFFFFu; q.heavy_items = 0; q.tier1_items = 0; q.tier1_wgs = 0; q.tier1_stride = 64;
+            q.sparse_wgs = 0;
+            // ---- heavy pixels
+            if (!(opt_sparse_stride > 0 && block.x >= 64)) return RT_OK;
+            const double mean = (double)rays_so_far / (double)n_pixels;                    // rays per pixel so far
             const unsigned int threshold = (unsigned int)(mean * (double)opt_heavy_factor_x10 / 10.0 + 0.999);
             const unsigned int threshold1 = (unsigned int)(mean * (double)opt_tier1_factor_x10 / 10.0 + 0.999);
             unsigned int* d_count = s->d_work_counter + 8;
@@ -578,42 +576,69 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             unsigned int count = 0;
             HIPCHK(hipMemcpyAsync(&count, d_count, sizeof(count), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
-            if (count > 0 && count <= RT_HEAVY_CAP && (size_t)count * 8 < n_pixels) {
-                s->h_heavy.resize(count);
-                HIPCHK(hipMemcpyAsync(s->h_heavy.data(), s->d_heavy_list, (size_t)count * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-                HIPCHK(hipStreamSynchronize(stream));
-                std::sort(s->h_heavy.begin(), s->h_heavy.end(), [](unsigned long long a, unsigned long long b) { return a > b; });
-                s->h_heavy_pixels.resize(count);
-                unsigned tier1_items = 0;
-                for (unsigned int q = 0; q < count; ++q) {
-                    s->h_heavy_pixels[q] = (unsigned int)(s->h_heavy[q] & 0xFFFFFFFFull);
-                    if ((unsigned int)(s->h_heavy[q] >> 32) >= threshold1) tier1_items = q + 1;
-                }
-                HIPCHK(hipMemcpyAsync(s->d_heavy_pixels, s->h_heavy_pixels.data(), (size_t)count * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
-                // workgroups: tier 1 = one live lane per wave, tier 2 = 64 / sparse_stride live lanes per wave
-                const unsigned waves_per_wg = block.x / 64u;
-                const unsigned max_grid = (unsigned)(g_num_cu * per_cu_resident);
-                const unsigned cap_wgs = max_grid * (unsigned)opt_sparse_wg_percent / 100u;
-                if (tier1_items > (unsigned)opt_tier1_pixels) tier1_items = (unsigned)opt_tier1_pixels;
-                unsigned tier1_wgs = (tier1_items + waves_per_wg - 1) / waves_per_wg;
-                if (tier1_wgs > cap_wgs / 2) { tier1_wgs = cap_wgs / 2; tier1_items = tier1_wgs * waves_per_wg; if (tier1_items > count) tier1_items = count; }
-                const unsigned tier2_items = count - tier1_items;
-                const unsigned per_wg2 = waves_per_wg * (64u / (unsigned)opt_sparse_stride);
-                unsigned tier2_wgs = (tier2_items + per_wg2 - 1) / per_wg2;
-                if (tier1_wgs + tier2_wgs > cap_wgs) tier2_wgs = cap_wgs - tier1_wgs;     // the rest of tier 2 queues behind them
-                const unsigned sparse_wgs = tier1_wgs + tier2_wgs;
-                const unsigned normal_need = (unsigned)((fp.work_items + block.x - 1) / block.x);
-                unsigned total = normal_need + sparse_wgs;
-                if (total > max_grid) total = max_grid;
-                if (sparse_wgs > 0 && total > sparse_wgs) {
-                    grid = dim3(total);
-                    fp.heavy_pixels = s->d_heavy_pixels; fp.heavy_threshold = threshold;
-                    fp.heavy_items = count; fp.tier1_items = tier1_items; fp.tier1_wgs = (int32_t)tier1_wgs; fp.tier1_stride = 64;
-                    fp.sparse_wgs = (int32_t)sparse_wgs; fp.sparse_stride = opt_sparse_stride;
-                    out.workgroups = (int)grid.x;
-                }
+            if (!(count > 0 && count <= RT_HEAVY_CAP && (size_t)count * 8 < n_pixels)) return RT_OK;
+            s->h_heavy.resize(count);
+            HIPCHK(hipMemcpyAsync(s->h_heavy.data(), s->d_heavy_list, (size_t)count * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            std::sort(s->h_heavy.begin(), s->h_heavy.end(), [](unsigned long long a, unsigned long long b) { return a > b; });
+            s->h_heavy_pixels.resize(count);
+            unsigned tier1_items = 0;
+            for (unsigned int k = 0; k < count; ++k) {
+                s->h_heavy_pixels[k] = (unsigned int)(s->h_heavy[k] & 0xFFFFFFFFull);
+                if ((unsigned int)(s->h_heavy[k] >> 32) >= threshold1) tier1_items = k + 1;
             }
+            HIPCHK(hipMemcpyAsync(s->d_heavy_pixels, s->h_heavy_pixels.data(), (size_t)count * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));   // h_heavy_pixels is reused by the next ranked part
+            // workgroups: tier 1 = one live lane per wave, tier 2 = 64 / sparse_stride live lanes per wave
+            const unsigned waves_per_wg = block.x / 64u;
+            const unsigned max_grid = (unsigned)(g_num_cu * per_cu_resident);
+            const unsigned cap_wgs = max_grid * (unsigned)opt_sparse_wg_percent / 100u;
+            if (tier1_items > (unsigned)opt_tier1_pixels) tier1_items = (unsigned)opt_tier1_pixels;
+            unsigned tier1_wgs = (tier1_items + waves_per_wg - 1) / waves_per_wg;
+            if (tier1_wgs > cap_wgs / 2) { tier1_wgs = cap_wgs / 2; tier1_items = tier1_wgs * waves_per_wg; if (tier1_items > count) tier1_items = count; }
+            const unsigned tier2_items = count - tier1_items;
+            const unsigned per_wg2 = waves_per_wg * (64u / (unsigned)opt_sparse_stride);
+            unsigned tier2_wgs = (tier2_items + per_wg2 - 1) / per_wg2;
+            if (tier1_wgs + tier2_wgs > cap_wgs) tier2_wgs = cap_wgs - tier1_wgs;     // the rest of tier 2 queues behind them
+            const unsigned sparse_wgs = tier1_wgs + tier2_wgs;
+            const unsigned normal_need = (unsigned)((q.work_items + block.x - 1) / block.x);
+            unsigned total = normal_need + sparse_wgs;
+            if (total > max_grid) total = max_grid;
+            if (sparse_wgs > 0 && total > sparse_wgs) {
+                grid_q = dim3(total);
+                q.heavy_pixels = s->d_heavy_pixels; q.heavy_threshold = threshold;
+                q.heavy_items = count; q.tier1_items = tier1_items; q.tier1_wgs = (int32_t)tier1_wgs; q.tier1_stride = 64;
+                q.sparse_wgs = (int32_t)sparse_wgs; q.sparse_stride = opt_sparse_stride;
+            }
+            return RT_OK;
+        };
+        // ---- part 1: samples [0, S_a) -- every pixel alike (nothing is known yet); S_a = presplit_samples, or S0
+        const int first_end = (opt_presplit_samples > 0 && opt_presplit_samples < opt_split_samples) ? opt_presplit_samples : opt_split_samples;
+        HIPCHK(hipMemsetAsync(s->d_tile_cost, 0, n_tiles * sizeof(unsigned int), stream));
+        HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
+        rt_frame_params p1 = fp;
+        p1.sample_end = first_end; p1.state_out = s->d_state; p1.tile_cost = s->d_tile_cost;
+        rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, p1, grid, block, lds_bytes, stream);
+        HIPCHK(hipGetLastError());
+        // ---- part 1b: samples [S_a, S0), already with tiers ranked on the first S_a samples.  Part 1 is bound by the
+        // chains of the dearest pixels run at an ordinary wave's pace; a short first look is enough to find most of them.
+        if (first_end < opt_split_samples) {
+            rt_frame_params p2 = fp;
+            dim3 grid2 = grid;
+            p2.sample_begin = first_end; p2.sample_end = opt_split_samples;
+            p2.state_in = s->d_state; p2.state_out = s->d_state; p2.tile_cost = s->d_tile_cost;
+            const rt_status st2 = rank_pixels(p2, grid2);
+            if (st2 != RT_OK) return st2;
+            HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
+            rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, p2, grid2, block, lds_bytes, stream);
+            HIPCHK(hipGetLastError());
         }
+        // ---- part 2: samples [S0, ns), ranked on the first S0 samples
+        split = true;
+        fp.state_in = s->d_state; fp.sample_begin = opt_split_samples;
+        const rt_status st3 = rank_pixels(fp, grid);
+        if (st3 != RT_OK) return st3;
+        out.workgroups = (int)grid.x;
     }
     (void)split;
     out.reserved = (int32_t)fp.heavy_items;

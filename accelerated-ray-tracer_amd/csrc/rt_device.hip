@@ -1060,7 +1060,18 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                 }
                 pcol = pcol + rad;
             }
-            if ((threadIdx.x & 63) == 0) { store_pixel(fp, i, lrow, pcol); rays += pixel_rays; }
+            if ((threadIdx.x & 63) == 0) {
+                if (fp.state_out) {   // a middle part of a split frame: park the pixel again
+                    rt_pixel_state so;
+                    so.rng[0] = pg.v0; so.rng[1] = pg.v1; so.rng[2] = pg.v2; so.rng[3] = pg.v3; so.rng[4] = pg.v4; so.rng[5] = pg.d;
+                    so.col[0] = pcol.x; so.col[1] = pcol.y; so.col[2] = pcol.z; so.cost = fp.state_in[pix].cost + pixel_rays;
+                    fp.state_out[pix] = so;
+                    atomicAdd(&fp.tile_cost[(lrow >> 3) * fp.tiles_x + (i >> 3)], pixel_rays);
+                } else {
+                    store_pixel(fp, i, lrow, pcol);
+                }
+                rays += pixel_rays;
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         sparse = false;   // tier-1 queue drained: this wave becomes an ordinary wave
@@ -1253,10 +1264,12 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                             // first part of a split frame: park the pixel at this sample boundary (no path is in flight
                             // here, so the XORWOW state and the colour sum are the whole state) and record what it cost
                             const unsigned int c = rays - rays_at_pixel_start;
+                            const size_t at = (size_t)px_lrow * fp.nx + px_i;
                             rt_pixel_state st;
                             st.rng[0] = g.v0; st.rng[1] = g.v1; st.rng[2] = g.v2; st.rng[3] = g.v3; st.rng[4] = g.v4; st.rng[5] = g.d;
-                            st.col[0] = col.x; st.col[1] = col.y; st.col[2] = col.z; st.cost = c;
-                            fp.state_out[(size_t)px_lrow * fp.nx + px_i] = st;
+                            st.col[0] = col.x; st.col[1] = col.y; st.col[2] = col.z;
+                            st.cost = c + (fp.state_in ? fp.state_in[at].cost : 0u);   // a middle part adds to what the pixel cost before
+                            fp.state_out[at] = st;
                             atomicAdd(&fp.tile_cost[(px_lrow >> 3) * fp.tiles_x + (px_i >> 3)], c);
                         } else {
                             store_pixel(fp, px_i, px_lrow, col);

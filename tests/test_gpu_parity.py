@@ -33,7 +33,7 @@ def render(art, hs, kernel=DEFAULT_KERNEL, opts=None, **frame_kw):
     art.set_option("kernel", kernel)
     defaults = {"lds_mode": -1, "steps_per_trip": 12, "shade_threshold": 32, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512,
                 "diel_threshold": 2, "box_threshold": 8, "medium_threshold": 16, "newpath_threshold": 24, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1,
-                "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 40, "heavy_max_tiles": 0, "tier1_pixels": 256, "tier1_factor_x10": 70, "split_samples": 32, "sparse_wg_percent": 35, "sparse_priority": 3,
+                "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 40, "heavy_max_tiles": 0, "tier1_pixels": 256, "tier1_factor_x10": 70, "split_samples": 32, "presplit_samples": 8, "sparse_wg_percent": 35, "sparse_priority": 3,
                 "sparse_eager": 0}
     defaults.update(opts or {})
     for k, v in defaults.items():
@@ -119,6 +119,7 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
     variants = [(3, {}), (3, {"lpt": 0}), (3, {"sparse_stride": 0}), (3, {"sparse_stride": 64, "heavy_factor_x10": 10, "sparse_wg_percent": 100}),
                 (3, {"sparse_stride": 2, "heavy_factor_x10": 12, "sparse_priority": 0, "sparse_eager": 1}), (3, {"tier1_pixels": 0, "sparse_stride": 16}),
                 (3, {"split_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096}), (3, {"split_samples": 3, "tier1_factor_x10": 15}),
+                (3, {"split_samples": 3, "presplit_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 12}), (3, {"split_samples": 2, "presplit_samples": 1, "tier1_pixels": 0}),
                 (3, {"lds_mode": 0}), (3, {"lds_mode": 3}), (3, {"lds_mode": 1}), (3, {"steps_per_trip": 1, "shade_threshold": 1, "diel_threshold": 1, "newpath_threshold": 1}),
                 (3, {"steps_per_trip": 11, "shade_threshold": 64, "diel_threshold": 64, "newpath_threshold": 64}), (3, {"threads": 256, "wg_per_cu": 3}),
                 (3, {"threads": 64, "wg_per_cu": 8, "shade_threshold": 40, "newpath_threshold": 3}),
@@ -252,7 +253,11 @@ def test_split_frame_schedule_matches_oracle(gpu, orc, name, nx, ny, ns):
     ref, cnt = orc.OracleScene(name, nx, ny, img, iw, ih).render(ns)
     for opts in ({"split_samples": 4, "heavy_factor_x10": 15, "tier1_factor_x10": 25, "tier1_pixels": 64, "sparse_stride": 8},
                  {"split_samples": 2, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096, "sparse_wg_percent": 100},
-                 {"split_samples": 3, "heavy_factor_x10": 12, "tier1_pixels": 0, "sparse_stride": 32, "sparse_priority": 0}):
+                 {"split_samples": 3, "heavy_factor_x10": 12, "tier1_pixels": 0, "sparse_stride": 32, "sparse_priority": 0},
+                 # three parts: a ranked middle part parks every pixel again, from ordinary, sparse and single-pixel waves
+                 {"split_samples": 4, "presplit_samples": 2, "heavy_factor_x10": 12, "tier1_factor_x10": 20, "tier1_pixels": 64},
+                 {"split_samples": 3, "presplit_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096, "sparse_wg_percent": 100},
+                 {"split_samples": 4, "presplit_samples": 3, "heavy_factor_x10": 11, "tier1_pixels": 0, "sparse_stride": 16}):
         fb, st = render(gpu, hs, 3, opts, ns=ns)
         assert st.rays == cnt["rays"], (opts, st.rays, cnt["rays"])
         assert_frames_equal(fb, ref, f"{name} {opts}")
