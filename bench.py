@@ -214,7 +214,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(kms, 3), "algorithmic_bytes_per_ray": bpr,
-                         "note": "scene is LDS-resident: algorithmic bytes are served by LDS, not HBM; kernel_ms is the device time of a step = the launches of the render kernel (two with the cost-aware schedule: samples [0,32) and [32,ns)), see DESIGN.md"},
+                         "note": "scene is LDS-resident: algorithmic bytes are served by LDS, not HBM; kernel_ms is the device time of a step = the launches of the render kernel (three with the cost-aware schedule: samples [0,8), [8,32) and [32,ns)) plus the ranking between them, see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.scene, args.nx, args.ny, args.cpu_ns)
