@@ -144,3 +144,26 @@ def test_long_chain_scenes_agree_in_the_mean(gpu, scene, ns, max_mae, min_corr):
     corr = float(np.corrcoef(box.ravel(), ref.ravel())[0, 1])
     print(scene, ns, "spp: box MAE", mae, "corr", corr)
     assert mae <= max_mae and corr >= min_corr, (mae, corr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,texture", [("quads", None), ("earth", "earthmap.ppm")])
+def test_drop_in_executable_prints_the_reference_image(gpu, scene, texture):
+    """End to end through the drop-in for src/main.cu's main(): `rayTracer --scene S` with the reference host function's
+    own nx, ny, ns prints the PPM whose pixels are the reference's published image (the pinned rows of it)."""
+    import subprocess
+    exe = os.path.join(gpu.LIB_DIR, "rayTracer")
+    cmd = [exe, "--scene", scene]
+    if texture:
+        cmd += ["--texture", os.path.join(gpu.REPO_ROOT, "assets", texture)]
+    r = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    info = META["images"][scene]
+    toks = r.stdout.decode().split()
+    assert toks[:4] == ["P3", str(info["nx"]), str(info["ny"]), "255"]
+    img = np.clip(np.array(toks[4:], np.int64).reshape(info["ny"], info["nx"], 3), 0, 255)   # top row first; PNG clips at 255
+    fb = img[::-1]
+    rows = [k for k in range(info["ny"]) if (k // TILE_ROWS) % TILE_STRIDE == TILE_FIRST]
+    s = match(fb[rows], PINS["rows_" + scene])
+    print(scene, s)
+    assert s["exact"] >= 0.9995 and s["within1"] == 1.0, s
