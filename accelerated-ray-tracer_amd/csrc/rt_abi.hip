@@ -36,6 +36,9 @@ int opt_medium_threshold = 16;
 int opt_newpath_threshold = 24;
 int opt_sparse_stride = 8;      // lanes per pixel in sparse waves (64 / live lanes); 0 disables sparse waves
 int opt_split_samples = 32;      // samples per pixel rendered before pixels are ranked by measured cost
+int opt_tier0_auto = 1;          // size the tiers from the share of the frame this call renders (see rank_pixels); 0 = the knobs as set
+int opt_tier0_pixels = 128;      // dearest pixels served one per WORKGROUP (tier 0, spheres-only scenes); 0 = off
+int opt_tier0_factor_x10 = 70;   // ... among those costing at least this multiple (x10) of the mean
 int opt_presplit_samples = 8;    // a first, shorter look: samples [presplit, split) already run with tiers ranked on it (0 = off)
 int opt_tier1_factor_x10 = 70;   // tier 1 = heavy pixels costing >= this/10 x the mean
 int opt_tier1_pixels = 256;      // heavy pixels served with one live lane per wave
@@ -251,6 +254,9 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "newpath_threshold") { if (value < 1 || value > 64) return invalid("newpath_threshold: 1..64"); opt_newpath_threshold = value; }
     else if (k == "sparse_stride") { if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return invalid("sparse_stride: 0, 2, 4, ... 64"); opt_sparse_stride = value; }
     else if (k == "heavy_factor_x10") { if (value < 10 || value > 1000) return invalid("heavy_factor_x10: 10..1000"); opt_heavy_factor_x10 = value; }
+    else if (k == "tier0_auto") { if (value < 0 || value > 1) return invalid("tier0_auto: 0 or 1"); opt_tier0_auto = value; }
+    else if (k == "tier0_pixels") { if (value < 0 || value > 4096) return invalid("tier0_pixels: 0..4096"); opt_tier0_pixels = value; }
+    else if (k == "tier0_factor_x10") { if (value < 10 || value > 10000) return invalid("tier0_factor_x10: 10..10000"); opt_tier0_factor_x10 = value; }
     else if (k == "presplit_samples") { if (value < 0 || value > 4096) return invalid("presplit_samples: 0..4096"); opt_presplit_samples = value; }
     else if (k == "split_samples") { if (value < 1 || value > 4096) return invalid("split_samples: 1..4096"); opt_split_samples = value; }
     else if (k == "tier1_factor_x10") { if (value < 10 || value > 10000) return invalid("tier1_factor_x10: 10..10000"); opt_tier1_factor_x10 = value; }
@@ -511,6 +517,18 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         grid = dim3(want < need ? want : need);
         per_cu_resident = per_cu;
     }
+    // tier 0 of the cost-aware schedule (spheres-only scenes resident in LDS): per-workgroup scratch behind the scene
+    // data -- header (16 B), 2 x 16 reduction slots (256 B), the leaf list (4 B per node: at most that many leaves)
+    fp.tier0_items = 0; fp.tier0_wgs = 0; fp.tier0_lds_offset = 0;
+    bool tier0_possible = false;
+    if (kernel == RT_KERNEL_STAGED && s->spheres_only && lds_mode == 2 && (opt_tier0_auto || opt_tier0_pixels > 0) && block.x >= 64 && block.x <= 1024) {
+        const size_t scratch = ((size_t)16 + 256 + (size_t)s->dev.n_nodes * 4 + 255) & ~(size_t)255;
+        if (lds_bytes + scratch + 512 <= g_lds_per_cu / (size_t)per_cu_resident) {
+            fp.tier0_lds_offset = (uint32_t)lds_bytes;
+            lds_bytes += scratch;
+            tier0_possible = true;
+        }
+    }
     out.kernel_variant = kernel * 1000 + lds_mode * 100 + s->tex_level * 10 + (s->spheres_only ? 1 : 0);
     out.workgroups = (int)grid.x; out.threads_per_group = (int)block.x; out.lds_bytes = (int)lds_bytes;
 
@@ -551,6 +569,19 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         // One ranked part: reads what the pixels cost so far, orders the tiles, lists the heavy pixels and sizes the
         // tiers for the launch described by `q` (which resumes every pixel from d_state).
         auto rank_pixels = [&](rt_frame_params& q, dim3& grid_q) -> rt_status {
+            // Effective tier sizes.  Whether a whole workgroup per ray pays depends on how much idle hardware there is per
+            // heavy pixel, i.e. on the share of the frame this call renders (1/N in an N-GPU run): measured on rank-local
+            // renders of the headline frame (tools/partition_time.py, profiles/r01i_partition_times.log) the whole frame
+            // is best with no tier 0 (it is throughput-bound; 132.5 vs 135-140 ms), half a frame with a moderate one,
+            // a quarter or less with every pixel above twice the mean on tier-0 workgroups (N = 8: 124.5 -> 85 ms).
+            int e_tier0_pixels = opt_tier0_pixels, e_tier0_factor = opt_tier0_factor_x10, e_tier1_pixels = opt_tier1_pixels,
+                e_heavy_factor = opt_heavy_factor_x10, e_sparse_percent = opt_sparse_wg_percent;
+            if (opt_tier0_auto) {
+                const double share = (double)n_pixels / ((double)f->nx * (double)f->ny);
+                if (share > 0.75) e_tier0_pixels = 0;
+                else if (share > 0.375) { e_tier0_pixels = 1024; e_tier0_factor = 40; e_tier1_pixels = 256; e_heavy_factor = 35; e_sparse_percent = 50; }
+                else { e_tier0_pixels = 4096; e_tier0_factor = 20; e_tier1_pixels = 0; e_heavy_factor = 20; e_sparse_percent = 80; }
+            }
             unsigned long long rays_so_far = 0;
             s->h_tile_cost.resize(n_tiles); s->h_tile_order.resize(n_tiles);
             HIPCHK(hipMemcpyAsync(s->h_tile_cost.data(), s->d_tile_cost, n_tiles * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
@@ -563,12 +594,13 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             HIPCHK(hipMemcpyAsync(s->d_tile_order, s->h_tile_order.data(), n_tiles * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
             q.tile_order = s->d_tile_order;
             q.heavy_pixels = nullptr; q.heavy_threshold = 0xFFFFFFFFu; q.heavy_items = 0; q.tier1_items = 0; q.tier1_wgs = 0; q.tier1_stride = 64;
-            q.sparse_wgs = 0;
+            q.sparse_wgs = 0; q.tier0_items = 0; q.tier0_wgs = 0;
             // ---- heavy pixels
             if (!(opt_sparse_stride > 0 && block.x >= 64)) return RT_OK;
             const double mean = (double)rays_so_far / (double)n_pixels;                    // rays per pixel so far
-            const unsigned int threshold = (unsigned int)(mean * (double)opt_heavy_factor_x10 / 10.0 + 0.999);
+            const unsigned int threshold = (unsigned int)(mean * (double)e_heavy_factor / 10.0 + 0.999);
             const unsigned int threshold1 = (unsigned int)(mean * (double)opt_tier1_factor_x10 / 10.0 + 0.999);
+            const unsigned int threshold0 = (unsigned int)(mean * (double)e_tier0_factor / 10.0 + 0.999);
             unsigned int* d_count = s->d_work_counter + 8;
             HIPCHK(hipMemsetAsync(d_count, 0, sizeof(unsigned int), stream));
             rt_launch_collect_heavy(s->d_state, (unsigned int)n_pixels, threshold, s->d_heavy_list, RT_HEAVY_CAP, d_count, stream);
@@ -582,25 +614,33 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             HIPCHK(hipStreamSynchronize(stream));
             std::sort(s->h_heavy.begin(), s->h_heavy.end(), [](unsigned long long a, unsigned long long b) { return a > b; });
             s->h_heavy_pixels.resize(count);
-            unsigned tier1_items = 0;
+            unsigned tier1_items = 0, tier0_items = 0;
             for (unsigned int k = 0; k < count; ++k) {
                 s->h_heavy_pixels[k] = (unsigned int)(s->h_heavy[k] & 0xFFFFFFFFull);
                 if ((unsigned int)(s->h_heavy[k] >> 32) >= threshold1) tier1_items = k + 1;
+                if ((unsigned int)(s->h_heavy[k] >> 32) >= threshold0) tier0_items = k + 1;
             }
             HIPCHK(hipMemcpyAsync(s->d_heavy_pixels, s->h_heavy_pixels.data(), (size_t)count * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
             HIPCHK(hipStreamSynchronize(stream));   // h_heavy_pixels is reused by the next ranked part
             // workgroups: tier 1 = one live lane per wave, tier 2 = 64 / sparse_stride live lanes per wave
             const unsigned waves_per_wg = block.x / 64u;
             const unsigned max_grid = (unsigned)(g_num_cu * per_cu_resident);
-            const unsigned cap_wgs = max_grid * (unsigned)opt_sparse_wg_percent / 100u;
-            if (tier1_items > (unsigned)opt_tier1_pixels) tier1_items = (unsigned)opt_tier1_pixels;
+            const unsigned cap_wgs = max_grid * (unsigned)e_sparse_percent / 100u;
+            // tier 0: the very dearest, one per workgroup (each workgroup serves its share of the list one pixel after the other)
+            unsigned tier0_wgs = 0;
+            if (!tier0_possible) tier0_items = 0;
+            if (tier0_items > (unsigned)e_tier0_pixels) tier0_items = (unsigned)e_tier0_pixels;
+            if (tier0_items > cap_wgs / 2) tier0_items = cap_wgs / 2;
+            tier0_wgs = tier0_items;
+            tier1_items = tier1_items > tier0_items ? tier1_items - tier0_items : 0;       // tier 1 follows tier 0 in the list
+            if (tier1_items > (unsigned)e_tier1_pixels) tier1_items = (unsigned)e_tier1_pixels;
             unsigned tier1_wgs = (tier1_items + waves_per_wg - 1) / waves_per_wg;
-            if (tier1_wgs > cap_wgs / 2) { tier1_wgs = cap_wgs / 2; tier1_items = tier1_wgs * waves_per_wg; if (tier1_items > count) tier1_items = count; }
-            const unsigned tier2_items = count - tier1_items;
+            if (tier0_wgs + tier1_wgs > cap_wgs / 2 + tier0_wgs / 2) { tier1_wgs = cap_wgs / 2 > tier0_wgs / 2 ? cap_wgs / 2 - tier0_wgs / 2 : 0; tier1_items = tier1_wgs * waves_per_wg; if (tier0_items + tier1_items > count) tier1_items = count - tier0_items; }
+            const unsigned tier2_items = count - tier0_items - tier1_items;
             const unsigned per_wg2 = waves_per_wg * (64u / (unsigned)opt_sparse_stride);
             unsigned tier2_wgs = (tier2_items + per_wg2 - 1) / per_wg2;
-            if (tier1_wgs + tier2_wgs > cap_wgs) tier2_wgs = cap_wgs - tier1_wgs;     // the rest of tier 2 queues behind them
-            const unsigned sparse_wgs = tier1_wgs + tier2_wgs;
+            if (tier0_wgs + tier1_wgs + tier2_wgs > cap_wgs) tier2_wgs = cap_wgs > tier0_wgs + tier1_wgs ? cap_wgs - tier0_wgs - tier1_wgs : 0;     // the rest of tier 2 queues behind them
+            const unsigned sparse_wgs = tier0_wgs + tier1_wgs + tier2_wgs;
             const unsigned normal_need = (unsigned)((q.work_items + block.x - 1) / block.x);
             unsigned total = normal_need + sparse_wgs;
             if (total > max_grid) total = max_grid;
@@ -608,6 +648,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
                 grid_q = dim3(total);
                 q.heavy_pixels = s->d_heavy_pixels; q.heavy_threshold = threshold;
                 q.heavy_items = count; q.tier1_items = tier1_items; q.tier1_wgs = (int32_t)tier1_wgs; q.tier1_stride = 64;
+                q.tier0_items = tier0_items; q.tier0_wgs = (int32_t)tier0_wgs;
                 q.sparse_wgs = (int32_t)sparse_wgs; q.sparse_stride = opt_sparse_stride;
             }
             return RT_OK;

@@ -48,6 +48,9 @@ struct rt_frame_params {
     uint32_t heavy_threshold;             // pixels whose parked cost is >= this are in heavy_pixels
     uint32_t tier1_items;                 // leading heavy_pixels entries served by tier-1 sparse workgroups
     int32_t tier1_wgs, tier1_stride;      // tier 1: the first tier1_wgs workgroups, one pixel per tier1_stride lanes
+    uint32_t tier0_items;                 // leading heavy_pixels entries served by tier-0 workgroups (one pixel per workgroup); tier 1 follows
+    int32_t tier0_wgs;                    // tier 0: the first tier0_wgs workgroups; tier 1: the next tier1_wgs
+    uint32_t tier0_lds_offset;            // tier 0: byte offset of the workgroup's scratch (leaf list, reduction slots) in dynamic LDS
     uint64_t seed_base;
     int32_t nx, ny, ns;
     float gamma;

@@ -612,6 +612,10 @@ DEV bool trace(const SceneView& sc, const Ray& r, HitInfo& best) {
     return best.prim >= 0;
 }
 
+DEV bool inv_is_finite(const f3 inv) {
+    return fabsf(inv.x) < INFINITY && fabsf(inv.y) < INFINITY && fabsf(inv.z) < INFINITY;
+}
+
 // One ray, the whole wave: the 64 lanes test 64 consecutive nodes of the depth-first array at once, then the walk the
 // reference would take through them (box hit -> next index or leaf test, box miss -> skip link) is replayed with scalar
 // bit tests on the ballot, v_readlane for the skip links.  Used by tier-1 waves, which hold a single pixel whose
@@ -654,6 +658,83 @@ DEV bool trace_wide(const SceneView& sc, const Ray& r, HitInfo& best) {
         i = j;
     }
     return best.prim >= 0;
+}
+
+
+// One ray, the whole workgroup ("tier 0", spheres-only scenes): every leaf of the tree is tested at once, one per
+// thread -- its own box with no limit, then its sphere -- and the closest hit is the minimum of (t, node index) over the
+// workgroup.  Why this is the reference's answer for finite 1/d:
+//   * a leaf the reference tests has a box that passes with the limit of that moment, hence with none: the set tested
+//     here is a superset of the reference's;
+//   * a box contains its descendants' boxes and the slab test is monotone in the box, so a leaf whose own box passes has
+//     ancestors that pass; the reference can only skip it because an earlier hit b satisfies b <= T_A <= T_leaf (entry
+//     distances).  The winner here has t <= every other candidate's t, so the b in force when the reference reaches its
+//     ancestors is >= t; if t > T_leaf (checked below) then b > T_A for every ancestor and the reference tests it too;
+//   * the reference keeps a hit only if t < closest, i.e. the minimum with ties to the first visited = lowest index.
+// A candidate hit at or before its own box's entry distance (rounding on a grazing ray) or a zero direction component
+// falls back to the reference's walk, replayed by every thread.  One barrier per ray (slots are double-buffered).
+DEV void slab_interval(const float4 lo_skip, const float4 hi_prim, const f3 o, const f3 inv, float tmin, float& t_enter, float& t_exit) {
+    float tmax = FLT_MAX;
+    float t0 = (lo_skip.x - o.x) * inv.x, t1 = (hi_prim.x - o.x) * inv.x;
+    if (inv.x < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
+    tmin = t0 > tmin ? t0 : tmin;
+    tmax = t1 < tmax ? t1 : tmax;
+    t0 = (lo_skip.y - o.y) * inv.y; t1 = (hi_prim.y - o.y) * inv.y;
+    if (inv.y < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
+    tmin = t0 > tmin ? t0 : tmin;
+    tmax = t1 < tmax ? t1 : tmax;
+    t0 = (lo_skip.z - o.z) * inv.z; t1 = (hi_prim.z - o.z) * inv.z;
+    if (inv.z < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
+    tmin = t0 > tmin ? t0 : tmin;
+    tmax = t1 < tmax ? t1 : tmax;
+    t_enter = tmin; t_exit = tmax;
+}
+DEV bool trace_group(const SceneView& sc, const Ray& r, HitInfo& best, const unsigned int* leaves, int n_leaves,
+                     unsigned long long* slots, int& parity) {
+    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const float tmin = 0.001f;
+    if (!inv_is_finite(inv)) return trace<true>(sc, r, best);   // workgroup-uniform
+    const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
+    unsigned long long key = ~0ull;
+    bool anomaly = false;
+    for (int q = (int)threadIdx.x; q < n_leaves; q += (int)blockDim.x) {
+        const int node = (int)leaves[q];
+        const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
+        float t_enter, t_exit;
+        slab_interval(a, b, r.o, inv, tmin, t_enter, t_exit);
+        if (!(t_exit <= t_enter)) {
+            float t;
+            if (sphere_test(sc.spheres[RT_PRIM_INDEX(__float_as_int(b.w))], r, tmin, FLT_MAX, t)) {
+                if (!(t > t_enter)) anomaly = true;
+                const unsigned long long k = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)node;
+                if (k < key) key = k;
+            }
+        }
+    }
+    if (anomaly) key = 0ull;
+    unsigned long long have = __ballot(key != ~0ull);
+    unsigned long long wkey = ~0ull;
+    const int lo = (int)(unsigned int)key, hi = (int)(unsigned int)(key >> 32);
+    while (have != 0ull) {
+        const int k = __ffsll((long long)have) - 1;
+        have &= have - 1ull;
+        const unsigned long long kk = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(hi, k) << 32) |
+                                      (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(lo, k);
+        if (kk < wkey) wkey = kk;
+    }
+    unsigned long long* mine = slots + parity * 16;
+    if ((threadIdx.x & 63u) == 0u) mine[threadIdx.x >> 6] = wkey;
+    __syncthreads();
+    unsigned long long m = ~0ull;
+    const int n_waves = (int)(blockDim.x >> 6);
+    for (int w = 0; w < n_waves; ++w) { const unsigned long long v = mine[w]; if (v < m) m = v; }
+    parity ^= 1;
+    if (m == 0ull) return trace<true>(sc, r, best);   // a grazing hit at or before its box's entry: the reference's walk decides
+    best.inst = -1;
+    if (m == ~0ull) { best.t = FLT_MAX; best.prim = -1; return false; }
+    best.t = __uint_as_float((unsigned int)(m >> 32));
+    best.prim = sc.nodes[(int)(unsigned int)m].prim;
+    return true;
 }
 
 }  // namespace
@@ -840,9 +921,6 @@ DEV bool slab_test_finite(const float4 lo_skip, const float4 hi_prim, const f3 o
     const float t_out = fminf(fminf(fminf(farx, fary), farz), tmax);
     return !(t_out <= t_in);
 }
-DEV bool inv_is_finite(const f3 inv) {
-    return fabsf(inv.x) < INFINITY && fabsf(inv.y) < INFINITY && fabsf(inv.z) < INFINITY;
-}
 }  // namespace
 
 template <bool SPHERES_ONLY, int TEX, bool NEED_UV, int LDS_MODE>
@@ -1024,14 +1102,41 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
     // Tier-1 waves hold ONE pixel each -- the dearest pixels of the frame, whose sequential chains bound the frame time.
     // With a single live lane the state machine below is pure overhead, so they run the reference's plain loop nest
     // (as kernel A does) on pixels parked by part 1, one after another, and only then join the ordinary waves.
-    if (sparse && (int)blockIdx.x < fp.tier1_wgs && fp.state_in) {
+    // Tier-0 workgroups (spheres-only scenes) go one step further for the very dearest pixels: the whole workgroup holds
+    // ONE pixel and every ray is traced by all its threads at once (trace_group()), which cuts the time per ray -- and
+    // with it the sequential chain that bounds the frame and every multi-GPU partition of it -- several times over.
+    const bool tier0 = SPHERES_ONLY && LDS_MODE == 2 && (int)blockIdx.x < fp.tier0_wgs && fp.state_in != nullptr;   // workgroup-uniform
+    const bool tier1 = sparse && !tier0 && (int)blockIdx.x < fp.tier0_wgs + fp.tier1_wgs && fp.state_in != nullptr;
+    if (tier0 || tier1) {
         __builtin_amdgcn_s_setprio(3);
-        // every lane of the wave carries the same pixel and computes the same values; only trace_wide() differs per lane
+        unsigned int* t0_scratch = reinterpret_cast<unsigned int*>(lds + fp.tier0_lds_offset);
+        unsigned long long* t0_slots = reinterpret_cast<unsigned long long*>(t0_scratch + 4);   // [2][16]
+        unsigned int* t0_leaves = t0_scratch + 4 + 64;
+        int t0_n_leaves = 0, t0_parity = 0;
+        if (tier0) {
+            if (threadIdx.x == 0) t0_scratch[0] = 0u;
+            __syncthreads();
+            for (int k = (int)threadIdx.x; k < n_nodes; k += (int)blockDim.x)
+                if (sc.nodes[k].prim >= 0) t0_leaves[atomicAdd(&t0_scratch[0], 1u)] = (unsigned int)k;
+            __syncthreads();
+            t0_n_leaves = (int)t0_scratch[0];
+        }
+        // every lane of the wave (tier 1) / thread of the workgroup (tier 0) carries the same pixel and computes the same
+        // values; only the traversal is shared out
         for (;;) {
             uint32_t idx = 0;
-            if ((threadIdx.x & 63) == 0) idx = atomicAdd(fp.work_counter + 2, 1u);
-            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-            if (idx >= fp.tier1_items) break;
+            if (tier0) {
+                if (threadIdx.x == 0) t0_scratch[1] = atomicAdd(fp.work_counter + 3, 1u);
+                __syncthreads();
+                idx = t0_scratch[1];
+                __syncthreads();
+                if (idx >= fp.tier0_items) break;
+            } else {
+                if ((threadIdx.x & 63) == 0) idx = atomicAdd(fp.work_counter + 2, 1u);
+                idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+                if (idx >= fp.tier1_items) break;
+                idx += fp.tier0_items;
+            }
             const uint32_t pix = fp.heavy_pixels[idx];
             const int lrow = (int)(pix / (uint32_t)fp.nx), i = (int)(pix - (uint32_t)lrow * (uint32_t)fp.nx);
             const int j = local_to_global_row(fp, lrow);
@@ -1048,7 +1153,8 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                 for (int depth = 0; depth < 50; ++depth) {                                   // main.cu:54-84
                     HitInfo h;
                     ++pixel_rays;
-                    if (!trace_wide<SPHERES_ONLY>(sc, r, h)) { rad = fma3(thr, miss_color(fp, r), rad); break; }
+                    const bool hit = tier0 ? trace_group(sc, r, h, t0_leaves, t0_n_leaves, t0_slots, t0_parity) : trace_wide<SPHERES_ONLY>(sc, r, h);
+                    if (!hit) { rad = fma3(thr, miss_color(fp, r), rad); break; }
                     const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, r, h);
                     f3 emitted, attenuation;
                     Ray scattered;
@@ -1060,7 +1166,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                 }
                 pcol = pcol + rad;
             }
-            if ((threadIdx.x & 63) == 0) {
+            if (tier0 ? threadIdx.x == 0 : (threadIdx.x & 63) == 0) {
                 if (fp.state_out) {   // a middle part of a split frame: park the pixel again
                     rt_pixel_state so;
                     so.rng[0] = pg.v0; so.rng[1] = pg.v1; so.rng[2] = pg.v2; so.rng[3] = pg.v3; so.rng[4] = pg.v4; so.rng[5] = pg.d;
@@ -1074,7 +1180,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        sparse = false;   // tier-1 queue drained: this wave becomes an ordinary wave
+        sparse = false;   // queue drained: this wave / workgroup becomes ordinary
     }
     // A sparse wave's few lanes are on the frame's critical path: let it win instruction-issue arbitration against the
     // three ordinary waves sharing its SIMD (priority outranks age, MI355X_MICROARCH.md "Two waves per SIMD").
@@ -1282,7 +1388,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                             // heavy list (sorted by descending cost): tier 1 = its first tier1_items entries
                             // tier 2 of the heavy list (tier 1 is served by the plain loop at the top of the kernel)
                             if (((threadIdx.x & 63) % (unsigned)fp.sparse_stride) != 0u) { alive = false; break; }
-                            const uint32_t at = fp.tier1_items + atomicAdd(fp.work_counter + 1, 1u);
+                            const uint32_t at = fp.tier0_items + fp.tier1_items + atomicAdd(fp.work_counter + 1, 1u);
                             if (at >= fp.heavy_items) { alive = false; break; }
                             const uint32_t pix = fp.heavy_pixels[at];
                             px_lrow = (int)(pix / (uint32_t)fp.nx); px_i = (int)(pix - (uint32_t)px_lrow * (uint32_t)fp.nx);

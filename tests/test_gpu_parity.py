@@ -33,7 +33,7 @@ def render(art, hs, kernel=DEFAULT_KERNEL, opts=None, **frame_kw):
     art.set_option("kernel", kernel)
     defaults = {"lds_mode": -1, "steps_per_trip": 12, "shade_threshold": 32, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512,
                 "diel_threshold": 2, "box_threshold": 8, "medium_threshold": 16, "newpath_threshold": 24, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1,
-                "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 40, "heavy_max_tiles": 0, "tier1_pixels": 256, "tier1_factor_x10": 70, "split_samples": 32, "presplit_samples": 8, "sparse_wg_percent": 35, "sparse_priority": 3,
+                "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 40, "heavy_max_tiles": 0, "tier1_pixels": 256, "tier1_factor_x10": 70, "split_samples": 32, "presplit_samples": 8, "tier0_auto": 0, "tier0_pixels": 128, "tier0_factor_x10": 70, "sparse_wg_percent": 35, "sparse_priority": 3,
                 "sparse_eager": 0}
     defaults.update(opts or {})
     for k, v in defaults.items():
@@ -106,6 +106,25 @@ def test_row_partition_is_invisible(gpu, orc):
     assert_frames_equal(whole, ref, "whole frame")
 
 
+def test_partitions_with_automatic_tier_sizing(gpu, orc):
+    """What each rank of a 2-, 4- or 8-GPU run does: the cost-aware schedule sizes its tiers from the share of the frame
+    (tier 0 = a whole workgroup per pixel for small shares).  Still the whole frame's pixels, bit for bit."""
+    nx, ny, ns = 240, 192, 16
+    hs = gpu.HostScene("bouncing", nx, ny)
+    ref, cnt = orc.OracleScene("bouncing", nx, ny).render(ns)
+    opts = {"tier0_auto": 1, "split_samples": 4, "presplit_samples": 2}
+    for world in (1, 2, 4, 8):
+        full = np.full((ny, nx, 3), np.nan, np.float32)
+        rays = 0
+        for r in range(world):
+            f_kw = dict(ns=ns, tile_rows=4 if world > 1 else ny, tile_first=r, tile_stride=world)
+            part, st = render(gpu, hs, DEFAULT_KERNEL, opts, **f_kw)
+            full[gpu.local_rows_to_global(hs.frame(**f_kw))] = part
+            rays += st.rays
+        assert rays == cnt["rays"], world
+        assert_frames_equal(full, ref, f"world {world}")
+
+
 def test_empty_partition(gpu):
     hs = gpu.HostScene("two_spheres", 16, 4)
     fb, st = render(gpu, hs, DEFAULT_KERNEL, ns=1, tile_rows=4, tile_first=3, tile_stride=4)   # only one tile exists
@@ -120,6 +139,7 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
                 (3, {"sparse_stride": 2, "heavy_factor_x10": 12, "sparse_priority": 0, "sparse_eager": 1}), (3, {"tier1_pixels": 0, "sparse_stride": 16}),
                 (3, {"split_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096}), (3, {"split_samples": 3, "tier1_factor_x10": 15}),
                 (3, {"split_samples": 3, "presplit_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 12}), (3, {"split_samples": 2, "presplit_samples": 1, "tier1_pixels": 0}),
+                (3, {"split_samples": 3, "tier0_factor_x10": 10, "tier0_pixels": 32, "heavy_factor_x10": 10}), (3, {"split_samples": 2, "tier0_pixels": 0}),
                 (3, {"lds_mode": 0}), (3, {"lds_mode": 3}), (3, {"lds_mode": 1}), (3, {"steps_per_trip": 1, "shade_threshold": 1, "diel_threshold": 1, "newpath_threshold": 1}),
                 (3, {"steps_per_trip": 11, "shade_threshold": 64, "diel_threshold": 64, "newpath_threshold": 64}), (3, {"threads": 256, "wg_per_cu": 3}),
                 (3, {"threads": 64, "wg_per_cu": 8, "shade_threshold": 40, "newpath_threshold": 3}),
@@ -257,7 +277,12 @@ def test_split_frame_schedule_matches_oracle(gpu, orc, name, nx, ny, ns):
                  # three parts: a ranked middle part parks every pixel again, from ordinary, sparse and single-pixel waves
                  {"split_samples": 4, "presplit_samples": 2, "heavy_factor_x10": 12, "tier1_factor_x10": 20, "tier1_pixels": 64},
                  {"split_samples": 3, "presplit_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096, "sparse_wg_percent": 100},
-                 {"split_samples": 4, "presplit_samples": 3, "heavy_factor_x10": 11, "tier1_pixels": 0, "sparse_stride": 16}):
+                 {"split_samples": 4, "presplit_samples": 3, "heavy_factor_x10": 11, "tier1_pixels": 0, "sparse_stride": 16},
+                 # tier 0 (whole workgroup per pixel, spheres-only scenes; ignored elsewhere) with and without the other tiers
+                 {"split_samples": 4, "presplit_samples": 2, "heavy_factor_x10": 10, "tier0_factor_x10": 10, "tier0_pixels": 64, "tier1_factor_x10": 10},
+                 {"split_samples": 2, "heavy_factor_x10": 12, "tier0_factor_x10": 15, "tier0_pixels": 16, "tier1_pixels": 0, "sparse_stride": 4},
+                 {"split_samples": 3, "heavy_factor_x10": 10, "tier0_factor_x10": 10, "tier0_pixels": 4096, "sparse_wg_percent": 100, "threads": 256, "wg_per_cu": 3},
+                 {"split_samples": 4, "tier0_pixels": 0, "heavy_factor_x10": 12}):
         fb, st = render(gpu, hs, 3, opts, ns=ns)
         assert st.rays == cnt["rays"], (opts, st.rays, cnt["rays"])
         assert_frames_equal(fb, ref, f"{name} {opts}")

@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import accelerated_ray_tracer_amd as art
 art.init(0)
+for kv in filter(None, os.environ.get("RT_OPTS", "").split(",")):   # A/B knobs: RT_OPTS=key=value,key=value
+    k, v = kv.split("="); art.set_option(k, int(v))
 hs = art.HostScene("random_scene", 1200, 800)
 ds = art.DeviceScene(hs)
 for stride in [int(x) for x in (sys.argv[1:] or ["1", "2", "4", "8"])]:
