@@ -1153,12 +1153,20 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                 for (int depth = 0; depth < 50; ++depth) {                                   // main.cu:54-84
                     HitInfo h;
                     ++pixel_rays;
+#ifdef RT_DIAG
+                    const unsigned long long dg0 = __builtin_readcyclecounter();
+#endif
                     const bool hit = tier0 ? trace_group(sc, r, h, t0_leaves, t0_n_leaves, t0_slots, t0_parity) : trace_wide<SPHERES_ONLY>(sc, r, h);
+#ifdef RT_DIAG
+                    const unsigned long long dg1 = __builtin_readcyclecounter();
+                    if (threadIdx.x == 0) { diag_local[15] += 1; diag_local[14] += dg1 - dg0; }   // slots 14/15: tier loops only
+#endif
                     if (!hit) { rad = fma3(thr, miss_color(fp, r), rad); break; }
                     const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, r, h);
                     f3 emitted, attenuation;
                     Ray scattered;
                     const bool go_on = shade<TEX>(sc, r, rec, pg, emitted, attenuation, scattered);
+
                     rad = fma3(thr, emitted, rad);
                     if (!go_on) break;
                     thr = thr * attenuation;
