@@ -71,7 +71,7 @@ MATERIAL_DTYPE = np.dtype([("kind", "<i4"), ("tex", "<i4"), ("fuzz", "<f4"), ("i
 # every symbol include/rt_abi.h declares
 RT_ABI_SYMBOLS = ["rt_init", "rt_shutdown", "rt_strerror", "rt_last_hip_error", "rt_last_error_detail", "rt_scene_create",
                   "rt_scene_destroy", "rt_frame_local_rows", "rt_local_to_global_row", "rt_render", "rt_frame_finish",
-                  "rt_set_option"]
+                  "rt_set_option", "rt_reset_options"]
 
 _rt = None
 _host = None
@@ -79,7 +79,7 @@ _host = None
 
 def build(verbose: bool = False) -> None:
     """Compile both libraries and the drop-in executable in-tree (hipcc --offload-arch=gfx950)."""
-    r = subprocess.run(["make", "-C", PKG_DIR, "-j4", "all"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", PKG_DIR, "-j8", "all"], capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout[-4000:])
         print(r.stderr[-4000:])
@@ -241,6 +241,11 @@ def init(device: int = 0) -> None:
 
 def set_option(key: str, value: int) -> None:
     _check(rt_lib().rt_set_option(key.encode(), int(value)), f"rt_set_option({key})")
+
+
+def reset_options() -> None:
+    """Every scheduling knob back to the shipped default."""
+    _check(rt_lib().rt_reset_options(), "rt_reset_options")
 
 
 class DeviceScene:

@@ -16,42 +16,52 @@
 
 namespace {
 
-int g_device = -1;
-int g_num_cu = 256;
-size_t g_lds_per_cu = 160 * 1024;
+// Devices this process has initialised (rt_init / rt_init_devices).  A scene remembers the device it was created on and
+// every entry point that touches it makes that device current first, so a caller may drive several devices from one
+// thread (rt_multi_*) or change the current device between calls.
+struct device_info {
+    bool ready = false;
+    int num_cu = 256;
+    size_t lds_per_cu = 160 * 1024;
+};
+enum { RT_MAX_DEVICES = 16 };
+device_info g_devices[RT_MAX_DEVICES];
+int g_device = -1;              // device new scenes are created on (the last rt_init)
 int g_last_hip_error = 0;
 std::string g_detail;
 
-// tuning knobs (rt_set_option)
-int opt_kernel = RT_KERNEL_STAGED;
-int opt_lds_mode = -1;          // -1 = choose from the scene size
-int opt_steps_per_trip = 12;
-int opt_shade_threshold = 32;
-int opt_wg_per_cu = 2;
-int opt_leaf_threshold = 1;
-int opt_threads = RT_PERSISTENT_THREADS;
-int opt_diel_threshold = 2;
-int opt_box_threshold = 8;
-int opt_medium_threshold = 16;
-int opt_newpath_threshold = 24;
-int opt_sparse_stride = 8;      // lanes per pixel in sparse waves (64 / live lanes); 0 disables sparse waves
-int opt_split_samples = 32;      // samples per pixel rendered before pixels are ranked by measured cost
-int opt_tier0_auto = 1;          // size the tiers from the share of the frame this call renders (see rank_pixels); 0 = the knobs as set
-int opt_tier0_pixels = 128;      // dearest pixels served one per WORKGROUP (tier 0, spheres-only scenes); 0 = off
-int opt_tier0_factor_x10 = 70;   // ... among those costing at least this multiple (x10) of the mean
-int opt_presplit_samples = 8;    // a first, shorter look: samples [presplit, split) already run with tiers ranked on it (0 = off)
-int opt_tier1_factor_x10 = 70;   // tier 1 = heavy pixels costing >= this/10 x the mean
-int opt_tier1_pixels = 256;      // heavy pixels served with one live lane per wave
-int opt_heavy_factor_x10 = 40;   // a pixel is "heavy" when its prepass ray count is >= this/10 x the mean
-int opt_heavy_max_tiles = 0;     // 0 = as many as the sparse workgroups hold at once
-int opt_sparse_priority = 3;
-int opt_sparse_eager = 0;
-int opt_sparse_wg_percent = 35;   // at most this share of the workgroups starts in sparse mode
-int opt_lpt = 1;                 // cost prepass + longest-first tile order (staged kernel, ns >= 16)
-int opt_wf_slots = 0;            // 0 = as many as fit in LDS (<= 1024)
-int opt_wf_pause_lanes = 32;
-int opt_wf_threads = 512;
-int opt_wf_wg_per_cu = 1;
+// Tuning knobs (rt_set_option); rt_reset_options() restores exactly these defaults, which are what ships.
+struct rt_options {
+    int kernel = RT_KERNEL_STAGED;
+    int lds_mode = -1;          // -1 = choose from the scene size
+    int steps_per_trip = 12;
+    int shade_threshold = 32;
+    int wg_per_cu = 2;
+    int threads = RT_PERSISTENT_THREADS;
+    int diel_threshold = 2;
+    int box_threshold = 8;
+    int medium_threshold = 16;
+    int newpath_threshold = 24;
+    int sparse_stride = 8;      // lanes per pixel in sparse waves (64 / live lanes); 0 disables sparse waves
+    int split_samples = 32;      // samples per pixel rendered before pixels are ranked by measured cost
+    int tier0_auto = 1;          // size the tiers from the share of the frame this call renders (see rank_pixels); 0 = the knobs as set
+    int tier0_pixels = 128;      // dearest pixels served one per WORKGROUP (tier 0, spheres-only scenes); 0 = off
+    int tier0_factor_x10 = 70;   // ... among those costing at least this multiple (x10) of the mean
+    int presplit_samples = 8;    // a first, shorter look: samples [presplit, split) already run with tiers ranked on it (0 = off)
+    int tier1_factor_x10 = 70;   // tier 1 = heavy pixels costing >= this/10 x the mean
+    int tier1_pixels = 256;      // heavy pixels served with one live lane per wave
+    int heavy_factor_x10 = 40;   // a pixel is "heavy" when its prepass ray count is >= this/10 x the mean
+    int heavy_max_tiles = 0;     // 0 = as many as the sparse workgroups hold at once
+    int sparse_priority = 3;
+    int sparse_eager = 0;
+    int sparse_wg_percent = 35;   // at most this share of the workgroups starts in sparse mode
+    int lpt = 1;                 // cost prepass + longest-first tile order (staged kernel, ns >= 2 * split_samples)
+    int wf_slots = 0;            // 0 = as many as fit in LDS (<= 1024)
+    int wf_pause_lanes = 32;
+    int wf_threads = 512;
+    int wf_wg_per_cu = 1;
+};
+rt_options g_opt;
 
 // the reference's checkCudaErrors (main.cu:23-35) records "<code> at file:line 'expr'"; it then
 // exits with 99, which a library must not do, so the status is returned instead.
@@ -87,6 +97,7 @@ rt_status upload(const T* src, size_t count, const T** dst) {
 }  // namespace
 
 struct rt_scene {
+    int device = 0;             // the device every allocation below lives on
     rt_scene_dev dev;
     std::vector<void*> allocs;
     bool spheres_only = false, need_uv = false;
@@ -112,6 +123,18 @@ struct rt_scene {
 };
 
 namespace {
+
+// picks the kernel family; LDS_MODE and texture level select the instantiation inside (rt_staged_*.hip)
+hipError_t launch_render(int kernel, int lds_mode, const rt_scene* s, const rt_frame_params& fp, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream) {
+    if (kernel == RT_KERNEL_PIXEL) return rt_launch_pixel(s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, grid, block, stream);
+    if (kernel == RT_KERNEL_WAVEFRONT) return rt_launch_wavefront(lds_mode, s->tex_level, s->dev, fp, grid, block, lds_bytes, stream);
+    if (s->spheres_only) {
+        if (s->tex_level <= 1) return rt_launch_staged_spheres(s->tex_level, lds_mode, s->dev, fp, grid, block, lds_bytes, stream);
+        return rt_launch_staged_spheres_tex(lds_mode, s->dev, fp, grid, block, lds_bytes, stream);
+    }
+    if (s->tex_level <= 1 && !s->need_uv) return rt_launch_staged_general(lds_mode, s->dev, fp, grid, block, lds_bytes, stream);
+    return rt_launch_staged_general_tex(lds_mode, s->dev, fp, grid, block, lds_bytes, stream);
+}
 
 bool simple_ref_ok(const rt_scene_desc* d, int32_t ref) {
     if (ref < 0) return false;
@@ -203,7 +226,8 @@ rt_status validate(const rt_scene_desc* d, bool& spheres_only, int& tex_level, b
 
 extern "C" {
 
-rt_status rt_init(int device_ordinal) {
+namespace {
+rt_status init_device(int device_ordinal) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
@@ -211,22 +235,43 @@ rt_status rt_init(int device_ordinal) {
         g_detail = "no HIP device visible (the render path has no CPU fallback)";
         return RT_ERR_NO_DEVICE;
     }
-    if (device_ordinal < 0 || device_ordinal >= count) return invalid("device ordinal out of range");
+    if (device_ordinal < 0 || device_ordinal >= count || device_ordinal >= RT_MAX_DEVICES) return invalid("device ordinal out of range");
     HIPCHK(hipSetDevice(device_ordinal));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_ordinal));
-    g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    g_lds_per_cu = prop.maxSharedMemoryPerMultiProcessor > 0 ? (size_t)prop.maxSharedMemoryPerMultiProcessor : (size_t)160 * 1024;
     if (!strstr(prop.gcnArchName, "gfx950")) {
         g_detail = std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only";
         return RT_ERR_NO_DEVICE;
     }
-    g_device = device_ordinal;
+    device_info& d = g_devices[device_ordinal];
+    d.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    d.lds_per_cu = prop.maxSharedMemoryPerMultiProcessor > 0 ? (size_t)prop.maxSharedMemoryPerMultiProcessor : (size_t)160 * 1024;
+    d.ready = true;
     return RT_OK;
+}
+// makes the scene's device current (a no-op when it already is)
+rt_status use_device(int device) {
+    if (device < 0 || device >= RT_MAX_DEVICES || !g_devices[device].ready) { g_detail = "rt_init has not succeeded for this device"; return RT_ERR_NO_DEVICE; }
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device) HIPCHK(hipSetDevice(device));
+    return RT_OK;
+}
+}  // namespace
+
+rt_status rt_init(int device_ordinal) {
+    const rt_status st = init_device(device_ordinal);
+    if (st == RT_OK) g_device = device_ordinal;
+    return st;
 }
 
 rt_status rt_shutdown(void) {
+    for (device_info& d : g_devices) d.ready = false;
     g_device = -1;
+    return RT_OK;
+}
+
+rt_status rt_reset_options(void) {
+    g_opt = rt_options();
     return RT_OK;
 }
 
@@ -246,41 +291,41 @@ const char* rt_last_error_detail(void) { return g_detail.c_str(); }
 rt_status rt_set_option(const char* key, int value) {
     if (!key) return invalid("null option key");
     const std::string k(key);
-    if (k == "kernel") { if (value < RT_KERNEL_PIXEL || value > RT_KERNEL_WAVEFRONT) return invalid("kernel: 0..4"); opt_kernel = value; }
-    else if (k == "leaf_threshold") { if (value < 1 || value > 64) return invalid("leaf_threshold: 1..64"); opt_leaf_threshold = value; }
-    else if (k == "box_threshold") { if (value < 1 || value > 64) return invalid("box_threshold: 1..64"); opt_box_threshold = value; }
-    else if (k == "medium_threshold") { if (value < 1 || value > 64) return invalid("medium_threshold: 1..64"); opt_medium_threshold = value; }
-    else if (k == "diel_threshold") { if (value < 1 || value > 64) return invalid("diel_threshold: 1..64"); opt_diel_threshold = value; }
-    else if (k == "newpath_threshold") { if (value < 1 || value > 64) return invalid("newpath_threshold: 1..64"); opt_newpath_threshold = value; }
-    else if (k == "sparse_stride") { if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return invalid("sparse_stride: 0, 2, 4, ... 64"); opt_sparse_stride = value; }
-    else if (k == "heavy_factor_x10") { if (value < 10 || value > 1000) return invalid("heavy_factor_x10: 10..1000"); opt_heavy_factor_x10 = value; }
-    else if (k == "tier0_auto") { if (value < 0 || value > 1) return invalid("tier0_auto: 0 or 1"); opt_tier0_auto = value; }
-    else if (k == "tier0_pixels") { if (value < 0 || value > 4096) return invalid("tier0_pixels: 0..4096"); opt_tier0_pixels = value; }
-    else if (k == "tier0_factor_x10") { if (value < 10 || value > 10000) return invalid("tier0_factor_x10: 10..10000"); opt_tier0_factor_x10 = value; }
-    else if (k == "presplit_samples") { if (value < 0 || value > 4096) return invalid("presplit_samples: 0..4096"); opt_presplit_samples = value; }
-    else if (k == "split_samples") { if (value < 1 || value > 4096) return invalid("split_samples: 1..4096"); opt_split_samples = value; }
-    else if (k == "tier1_factor_x10") { if (value < 10 || value > 10000) return invalid("tier1_factor_x10: 10..10000"); opt_tier1_factor_x10 = value; }
-    else if (k == "tier1_pixels") { if (value < 0 || value > 8192) return invalid("tier1_pixels: 0..8192"); opt_tier1_pixels = value; }
-    else if (k == "sparse_eager") { if (value < 0 || value > 1) return invalid("sparse_eager: 0 or 1"); opt_sparse_eager = value; }
-    else if (k == "sparse_priority") { if (value < 0 || value > 3) return invalid("sparse_priority: 0..3"); opt_sparse_priority = value; }
-    else if (k == "sparse_wg_percent") { if (value < 1 || value > 100) return invalid("sparse_wg_percent: 1..100"); opt_sparse_wg_percent = value; }
-    else if (k == "heavy_max_tiles") { if (value < 0 || value > 4096) return invalid("heavy_max_tiles: 0..4096"); opt_heavy_max_tiles = value; }
-    else if (k == "lpt") { if (value < 0 || value > 1) return invalid("lpt: 0 or 1"); opt_lpt = value; }
-    else if (k == "wf_slots") { if (value < 0 || value > 4096 || (value % 64)) return invalid("wf_slots: 0 or a multiple of 64 up to 4096"); opt_wf_slots = value; }
-    else if (k == "wf_threads") { if (value != 256 && value != 512 && value != 768 && value != 1024) return invalid("wf_threads: 256, 512, 768 or 1024"); opt_wf_threads = value; }
-    else if (k == "wf_wg_per_cu") { if (value < 1 || value > 8) return invalid("wf_wg_per_cu: 1..8"); opt_wf_wg_per_cu = value; }
-    else if (k == "wf_pause_lanes") { if (value < 1 || value > 64) return invalid("wf_pause_lanes: 1..64"); opt_wf_pause_lanes = value; }
-    else if (k == "threads") { if (value != 64 && value != 128 && value != 256 && value != 512) return invalid("threads: 64, 128, 256 or 512"); opt_threads = value; }
-    else if (k == "lds_mode") { if (value < -1 || value > 3) return invalid("lds_mode: -1..3"); opt_lds_mode = value; }
-    else if (k == "steps_per_trip") { if (value < 1 || value > 64) return invalid("steps_per_trip: 1..64"); opt_steps_per_trip = value; }
-    else if (k == "shade_threshold") { if (value < 1 || value > 64) return invalid("shade_threshold: 1..64"); opt_shade_threshold = value; }
-    else if (k == "wg_per_cu") { if (value < 1 || value > 8) return invalid("wg_per_cu: 1..8"); opt_wg_per_cu = value; }
+    if (k == "kernel") { if (value != RT_KERNEL_PIXEL && value != RT_KERNEL_STAGED && value != RT_KERNEL_WAVEFRONT) return invalid("kernel: 0 (pixel), 3 (staged) or 4 (wavefront)"); g_opt.kernel = value; }
+    else if (k == "box_threshold") { if (value < 1 || value > 64) return invalid("box_threshold: 1..64"); g_opt.box_threshold = value; }
+    else if (k == "medium_threshold") { if (value < 1 || value > 64) return invalid("medium_threshold: 1..64"); g_opt.medium_threshold = value; }
+    else if (k == "diel_threshold") { if (value < 1 || value > 64) return invalid("diel_threshold: 1..64"); g_opt.diel_threshold = value; }
+    else if (k == "newpath_threshold") { if (value < 1 || value > 64) return invalid("newpath_threshold: 1..64"); g_opt.newpath_threshold = value; }
+    else if (k == "sparse_stride") { if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return invalid("sparse_stride: 0, 2, 4, ... 64"); g_opt.sparse_stride = value; }
+    else if (k == "heavy_factor_x10") { if (value < 10 || value > 1000) return invalid("heavy_factor_x10: 10..1000"); g_opt.heavy_factor_x10 = value; }
+    else if (k == "tier0_auto") { if (value < 0 || value > 1) return invalid("tier0_auto: 0 or 1"); g_opt.tier0_auto = value; }
+    else if (k == "tier0_pixels") { if (value < 0 || value > 4096) return invalid("tier0_pixels: 0..4096"); g_opt.tier0_pixels = value; }
+    else if (k == "tier0_factor_x10") { if (value < 10 || value > 10000) return invalid("tier0_factor_x10: 10..10000"); g_opt.tier0_factor_x10 = value; }
+    else if (k == "presplit_samples") { if (value < 0 || value > 4096) return invalid("presplit_samples: 0..4096"); g_opt.presplit_samples = value; }
+    else if (k == "split_samples") { if (value < 1 || value > 4096) return invalid("split_samples: 1..4096"); g_opt.split_samples = value; }
+    else if (k == "tier1_factor_x10") { if (value < 10 || value > 10000) return invalid("tier1_factor_x10: 10..10000"); g_opt.tier1_factor_x10 = value; }
+    else if (k == "tier1_pixels") { if (value < 0 || value > 8192) return invalid("tier1_pixels: 0..8192"); g_opt.tier1_pixels = value; }
+    else if (k == "sparse_eager") { if (value < 0 || value > 1) return invalid("sparse_eager: 0 or 1"); g_opt.sparse_eager = value; }
+    else if (k == "sparse_priority") { if (value < 0 || value > 3) return invalid("sparse_priority: 0..3"); g_opt.sparse_priority = value; }
+    else if (k == "sparse_wg_percent") { if (value < 1 || value > 100) return invalid("sparse_wg_percent: 1..100"); g_opt.sparse_wg_percent = value; }
+    else if (k == "heavy_max_tiles") { if (value < 0 || value > 4096) return invalid("heavy_max_tiles: 0..4096"); g_opt.heavy_max_tiles = value; }
+    else if (k == "lpt") { if (value < 0 || value > 1) return invalid("lpt: 0 or 1"); g_opt.lpt = value; }
+    else if (k == "wf_slots") { if (value < 0 || value > 4096 || (value % 64)) return invalid("wf_slots: 0 or a multiple of 64 up to 4096"); g_opt.wf_slots = value; }
+    else if (k == "wf_threads") { if (value != 256 && value != 512 && value != 768 && value != 1024) return invalid("wf_threads: 256, 512, 768 or 1024"); g_opt.wf_threads = value; }
+    else if (k == "wf_wg_per_cu") { if (value < 1 || value > 8) return invalid("wf_wg_per_cu: 1..8"); g_opt.wf_wg_per_cu = value; }
+    else if (k == "wf_pause_lanes") { if (value < 1 || value > 64) return invalid("wf_pause_lanes: 1..64"); g_opt.wf_pause_lanes = value; }
+    else if (k == "threads") { if (value != 64 && value != 128 && value != 256 && value != 512) return invalid("threads: 64, 128, 256 or 512"); g_opt.threads = value; }
+    else if (k == "lds_mode") { if (value < -1 || value > 3) return invalid("lds_mode: -1..3"); g_opt.lds_mode = value; }
+    else if (k == "steps_per_trip") { if (value < 1 || value > 64) return invalid("steps_per_trip: 1..64"); g_opt.steps_per_trip = value; }
+    else if (k == "shade_threshold") { if (value < 1 || value > 64) return invalid("shade_threshold: 1..64"); g_opt.shade_threshold = value; }
+    else if (k == "wg_per_cu") { if (value < 1 || value > 8) return invalid("wg_per_cu: 1..8"); g_opt.wg_per_cu = value; }
     else return invalid("unknown option");
     return RT_OK;
 }
 
 rt_status rt_scene_destroy(rt_scene* s) {
     if (!s) return RT_OK;
+    (void)use_device(s->device);
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->d_ray_counter) (void)hipFree(s->d_ray_counter);
     if (s->d_work_counter) (void)hipFree(s->d_work_counter);
@@ -300,12 +345,14 @@ rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!out) return invalid("null output pointer");
     *out = nullptr;
     if (g_device < 0) { g_detail = "rt_init has not succeeded"; return RT_ERR_NO_DEVICE; }
+    { const rt_status ud = use_device(g_device); if (ud != RT_OK) return ud; }
     bool so = false, uv = false;
     int tx = 0;
     rt_status st = validate(d, so, tx, uv);
     if (st != RT_OK) return st;
 
     rt_scene* s = new rt_scene;
+    s->device = g_device;
     memset(&s->dev, 0, sizeof(s->dev));
     memset(&s->pending_stats, 0, sizeof(s->pending_stats));
     s->spheres_only = so; s->tex_level = tx; s->need_uv = uv;
@@ -364,6 +411,7 @@ int32_t rt_local_to_global_row(const rt_frame_desc* f, int32_t local_row) {
 rt_status rt_frame_finish(rt_scene* s, rt_stats* stats) {
     if (!s) return invalid("null scene");
     if (!s->frame_pending) { if (stats) *stats = s->pending_stats; return RT_OK; }
+    { const rt_status ud = use_device(s->device); if (ud != RT_OK) return ud; }
     HIPCHK(hipEventSynchronize(s->ev_stop));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
@@ -381,13 +429,16 @@ rt_status rt_frame_finish(rt_scene* s, rt_stats* stats) {
 // Diagnostic builds (-DRT_DIAG) leave per-stage execution counts behind the ray counter; 16 values.
 rt_status rt_debug_counters(rt_scene* s, unsigned long long* out16) {
     if (!s || !out16) return invalid("null argument");
+    { const rt_status ud = use_device(s->device); if (ud != RT_OK) return ud; }
     HIPCHK(hipMemcpy(out16, s->d_ray_counter + 1, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
 rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_device, void* stream_v, int blocking, rt_stats* stats) {
     if (!s || !f || !fb) return invalid("null argument");
-    if (g_device < 0) { g_detail = "rt_init has not succeeded"; return RT_ERR_NO_DEVICE; }
+    { const rt_status ud = use_device(s->device); if (ud != RT_OK) return ud; }
+    const int g_num_cu = g_devices[s->device].num_cu;
+    const size_t g_lds_per_cu = g_devices[s->device].lds_per_cu;
     if (f->nx <= 0 || f->ny <= 0 || f->ns <= 0) return invalid("nx, ny and ns must be positive");
     if ((long long)f->nx * f->ny >= (1ll << 31)) return invalid("frame too large");
     const int local_rows = rt_frame_local_rows(f);
@@ -426,16 +477,15 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     const int tiles_y = (local_rows + 7) / 8;
     if ((long long)fp.tiles_x * tiles_y * 64 >= (1ll << 31)) return invalid("frame too large");
     fp.work_items = (uint32_t)fp.tiles_x * (uint32_t)tiles_y * 64u;
-    fp.heavy_items = 0; fp.sparse_wgs = 0; fp.sparse_stride = 1; fp.sparse_priority = opt_sparse_priority; fp.sparse_eager = opt_sparse_eager;
-    fp.steps_per_trip = opt_steps_per_trip;
-    fp.shade_threshold = opt_shade_threshold;
-    fp.leaf_threshold = opt_leaf_threshold;
-    fp.diel_threshold = opt_diel_threshold;
-    fp.box_threshold = opt_box_threshold; fp.medium_threshold = opt_medium_threshold;
-    fp.newpath_threshold = opt_newpath_threshold;
+    fp.heavy_items = 0; fp.sparse_wgs = 0; fp.sparse_stride = 1; fp.sparse_priority = g_opt.sparse_priority; fp.sparse_eager = g_opt.sparse_eager;
+    fp.steps_per_trip = g_opt.steps_per_trip;
+    fp.shade_threshold = g_opt.shade_threshold;
+    fp.diel_threshold = g_opt.diel_threshold;
+    fp.box_threshold = g_opt.box_threshold; fp.medium_threshold = g_opt.medium_threshold;
+    fp.newpath_threshold = g_opt.newpath_threshold;
 
     // LDS residency: nodes + spheres if two workgroups still fit a CU, else nodes only, else none
-    int lds_mode = opt_lds_mode;
+    int lds_mode = g_opt.lds_mode;
     const size_t budget2 = g_lds_per_cu / 2 - 1024, budget1 = g_lds_per_cu - 2048;
     if (lds_mode < 0) {
         // (lds_mode 3 -- materials and textures in LDS too -- is selectable but measured no faster: profiles/r01_sweep34)
@@ -445,7 +495,8 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         else if (s->node_bytes <= budget1) lds_mode = 1;
         else lds_mode = 0;
     }
-    if (lds_mode == 3 && opt_kernel != RT_KERNEL_STAGED) lds_mode = 2;
+    if (lds_mode == 3 && g_opt.kernel != RT_KERNEL_STAGED) lds_mode = 2;
+    if (g_opt.kernel == RT_KERNEL_PIXEL) lds_mode = 0;   // the cross-check kernel reads the scene through L1/L2
     size_t lds_bytes = 0;
     if (lds_mode >= 1) lds_bytes += s->node_bytes;
     if (lds_mode >= 2) lds_bytes += s->sphere_bytes;
@@ -454,12 +505,12 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
 
     // the wavefront kernel covers spheres-only scenes with inline/solid/checker textures and frames whose
     // pixel coordinates pack into 16 bits each; everything else runs the staged kernel
-    int kernel = opt_kernel;
+    int kernel = g_opt.kernel;
     if (kernel == RT_KERNEL_WAVEFRONT && !(s->spheres_only && s->tex_level <= 1 && f->nx <= 65535 && local_rows <= 65535)) kernel = RT_KERNEL_STAGED;
     int wf_slots = 0;
     if (kernel == RT_KERNEL_WAVEFRONT) {
-        const int threads = opt_wf_threads;
-        const size_t cap = g_lds_per_cu / (size_t)opt_wf_wg_per_cu - 1024;
+        const int threads = g_opt.wf_threads;
+        const size_t cap = g_lds_per_cu / (size_t)g_opt.wf_wg_per_cu - 1024;
         // prefer nodes + spheres in LDS; drop spheres to L1/L2 if that is what it takes to get >= 1.5 slots per lane
         for (int attempt = 0; attempt < 2 && wf_slots == 0; ++attempt) {
             size_t scene = 0;
@@ -469,16 +520,16 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             long fit = scene + 256 < cap ? (long)((cap - scene - 256) / RT_WF_BYTES_PER_SLOT) : 0;
             fit = fit / 64 * 64;
             if (fit > 2048) fit = 2048;
-            if (opt_wf_slots) { if (opt_wf_slots <= fit) fit = opt_wf_slots; else fit = 0; }
+            if (g_opt.wf_slots) { if (g_opt.wf_slots <= fit) fit = g_opt.wf_slots; else fit = 0; }
             if (fit >= threads + threads / 4 || (attempt == 1 && fit >= threads)) { wf_slots = (int)fit; lds_bytes = scene + (size_t)fit * RT_WF_BYTES_PER_SLOT + 256; }
             else if (lds_mode == 2) lds_mode = 1;
             else break;
         }
-        if (wf_slots == 0) { kernel = RT_KERNEL_STAGED; lds_mode = opt_lds_mode; }
+        if (wf_slots == 0) { kernel = RT_KERNEL_STAGED; lds_mode = g_opt.lds_mode; }
     }
-    if (kernel != opt_kernel && kernel == RT_KERNEL_STAGED && opt_kernel == RT_KERNEL_WAVEFRONT) {
+    if (kernel != g_opt.kernel && kernel == RT_KERNEL_STAGED && g_opt.kernel == RT_KERNEL_WAVEFRONT) {
         // recompute the plain LDS plan for the fallback
-        lds_mode = opt_lds_mode;
+        lds_mode = g_opt.lds_mode;
         if (lds_mode < 0) {
             if (s->node_bytes + s->sphere_bytes <= budget2) lds_mode = 2;
             else if (s->node_bytes <= budget2) lds_mode = 1;
@@ -491,7 +542,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         if (lds_mode >= 2) lds_bytes += s->sphere_bytes;
     }
     fp.wf_slots = wf_slots;
-    fp.wf_pause_lanes = opt_wf_pause_lanes;
+    fp.wf_pause_lanes = g_opt.wf_pause_lanes;
     {   // generous bound: every live slot retires a ray segment (or a paused walk advances) each iteration
         const double segs = (double)local_rows * f->nx * (double)f->ns * 51.0;
         const double per_wg = segs / (wf_slots > 0 ? wf_slots : 1) * 4.0 + 100000.0;
@@ -501,19 +552,19 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     dim3 grid, block;
     int per_cu_resident = 1;   // workgroups of this launch that can be resident on one CU (persistent kernels)
     if (kernel == RT_KERNEL_WAVEFRONT) {
-        block = dim3(opt_wf_threads);
+        block = dim3(g_opt.wf_threads);
         const unsigned need = (fp.work_items + (unsigned)wf_slots - 1) / (unsigned)wf_slots;
-        const unsigned want = (unsigned)(g_num_cu * opt_wf_wg_per_cu);
+        const unsigned want = (unsigned)(g_num_cu * g_opt.wf_wg_per_cu);
         grid = dim3(want < need ? want : need);
     } else if (kernel == RT_KERNEL_PIXEL) {
         block = dim3(256);
         grid = dim3((fp.work_items + 255u) / 256u);
     } else {
-        block = dim3(kernel == RT_KERNEL_PIXEL ? 256 : opt_threads);
-        int per_cu = opt_wg_per_cu;
+        block = dim3(kernel == RT_KERNEL_PIXEL ? 256 : g_opt.threads);
+        int per_cu = g_opt.wg_per_cu;
         if (lds_bytes) { const int fit = (int)(g_lds_per_cu / (lds_bytes + 512)); if (fit < per_cu) per_cu = fit < 1 ? 1 : fit; }
         unsigned want = (unsigned)(g_num_cu * per_cu);
-        const unsigned need = (fp.work_items + opt_threads - 1) / opt_threads;
+        const unsigned need = (fp.work_items + g_opt.threads - 1) / g_opt.threads;
         grid = dim3(want < need ? want : need);
         per_cu_resident = per_cu;
     }
@@ -521,7 +572,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     // data -- header (16 B), 2 x 16 reduction slots (256 B), the leaf list (4 B per node: at most that many leaves)
     fp.tier0_items = 0; fp.tier0_wgs = 0; fp.tier0_lds_offset = 0;
     bool tier0_possible = false;
-    if (kernel == RT_KERNEL_STAGED && s->spheres_only && lds_mode == 2 && (opt_tier0_auto || opt_tier0_pixels > 0) && block.x >= 64 && block.x <= 1024) {
+    if (kernel == RT_KERNEL_STAGED && s->spheres_only && lds_mode == 2 && (g_opt.tier0_auto || g_opt.tier0_pixels > 0) && block.x >= 64 && block.x <= 1024) {
         const size_t scratch = ((size_t)16 + 256 + (size_t)s->dev.n_nodes * 4 + 255) & ~(size_t)255;
         if (lds_bytes + scratch + 512 <= g_lds_per_cu / (size_t)per_cu_resident) {
             fp.tier0_lds_offset = (uint32_t)lds_bytes;
@@ -553,7 +604,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     enum { RT_HEAVY_CAP = 32768 };
     bool split = false;
     HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 256, stream));
-    if (opt_lpt && kernel == RT_KERNEL_STAGED && f->ns >= 2 * opt_split_samples && n_tiles >= 64 && n_pixels < (1ull << 31)) {
+    if (g_opt.lpt && kernel == RT_KERNEL_STAGED && f->ns >= 2 * g_opt.split_samples && n_tiles >= 64 && n_pixels < (1ull << 31)) {
         if (s->tile_capacity < n_tiles || s->pixel_capacity < n_pixels) {
             for (void* p : {(void*)s->d_tile_cost, (void*)s->d_tile_order, (void*)s->d_state, (void*)s->d_heavy_list, (void*)s->d_heavy_pixels})
                 if (p) (void)hipFree(p);
@@ -574,9 +625,9 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             // renders of the headline frame (tools/partition_time.py, profiles/r01i_partition_times.log) the whole frame
             // is best with no tier 0 (it is throughput-bound; 132.5 vs 135-140 ms), half a frame with a moderate one,
             // a quarter or less with every pixel above twice the mean on tier-0 workgroups (N = 8: 124.5 -> 85 ms).
-            int e_tier0_pixels = opt_tier0_pixels, e_tier0_factor = opt_tier0_factor_x10, e_tier1_pixels = opt_tier1_pixels,
-                e_heavy_factor = opt_heavy_factor_x10, e_sparse_percent = opt_sparse_wg_percent;
-            if (opt_tier0_auto) {
+            int e_tier0_pixels = g_opt.tier0_pixels, e_tier0_factor = g_opt.tier0_factor_x10, e_tier1_pixels = g_opt.tier1_pixels,
+                e_heavy_factor = g_opt.heavy_factor_x10, e_sparse_percent = g_opt.sparse_wg_percent;
+            if (g_opt.tier0_auto) {
                 const double share = (double)n_pixels / ((double)f->nx * (double)f->ny);
                 if (share > 0.75) e_tier0_pixels = 0;
                 else if (share > 0.375) { e_tier0_pixels = 1024; e_tier0_factor = 40; e_tier1_pixels = 256; e_heavy_factor = 35; e_sparse_percent = 50; }
@@ -596,10 +647,10 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             q.heavy_pixels = nullptr; q.heavy_threshold = 0xFFFFFFFFu; q.heavy_items = 0; q.tier1_items = 0; q.tier1_wgs = 0; q.tier1_stride = 64;
             q.sparse_wgs = 0; q.tier0_items = 0; q.tier0_wgs = 0;
             // ---- heavy pixels
-            if (!(opt_sparse_stride > 0 && block.x >= 64)) return RT_OK;
+            if (!(g_opt.sparse_stride > 0 && block.x >= 64)) return RT_OK;
             const double mean = (double)rays_so_far / (double)n_pixels;                    // rays per pixel so far
             const unsigned int threshold = (unsigned int)(mean * (double)e_heavy_factor / 10.0 + 0.999);
-            const unsigned int threshold1 = (unsigned int)(mean * (double)opt_tier1_factor_x10 / 10.0 + 0.999);
+            const unsigned int threshold1 = (unsigned int)(mean * (double)g_opt.tier1_factor_x10 / 10.0 + 0.999);
             const unsigned int threshold0 = (unsigned int)(mean * (double)e_tier0_factor / 10.0 + 0.999);
             unsigned int* d_count = s->d_work_counter + 8;
             HIPCHK(hipMemsetAsync(d_count, 0, sizeof(unsigned int), stream));
@@ -637,7 +688,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             unsigned tier1_wgs = (tier1_items + waves_per_wg - 1) / waves_per_wg;
             if (tier0_wgs + tier1_wgs > cap_wgs / 2 + tier0_wgs / 2) { tier1_wgs = cap_wgs / 2 > tier0_wgs / 2 ? cap_wgs / 2 - tier0_wgs / 2 : 0; tier1_items = tier1_wgs * waves_per_wg; if (tier0_items + tier1_items > count) tier1_items = count - tier0_items; }
             const unsigned tier2_items = count - tier0_items - tier1_items;
-            const unsigned per_wg2 = waves_per_wg * (64u / (unsigned)opt_sparse_stride);
+            const unsigned per_wg2 = waves_per_wg * (64u / (unsigned)g_opt.sparse_stride);
             unsigned tier2_wgs = (tier2_items + per_wg2 - 1) / per_wg2;
             if (tier0_wgs + tier1_wgs + tier2_wgs > cap_wgs) tier2_wgs = cap_wgs > tier0_wgs + tier1_wgs ? cap_wgs - tier0_wgs - tier1_wgs : 0;     // the rest of tier 2 queues behind them
             const unsigned sparse_wgs = tier0_wgs + tier1_wgs + tier2_wgs;
@@ -649,34 +700,32 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
                 q.heavy_pixels = s->d_heavy_pixels; q.heavy_threshold = threshold;
                 q.heavy_items = count; q.tier1_items = tier1_items; q.tier1_wgs = (int32_t)tier1_wgs; q.tier1_stride = 64;
                 q.tier0_items = tier0_items; q.tier0_wgs = (int32_t)tier0_wgs;
-                q.sparse_wgs = (int32_t)sparse_wgs; q.sparse_stride = opt_sparse_stride;
+                q.sparse_wgs = (int32_t)sparse_wgs; q.sparse_stride = g_opt.sparse_stride;
             }
             return RT_OK;
         };
         // ---- part 1: samples [0, S_a) -- every pixel alike (nothing is known yet); S_a = presplit_samples, or S0
-        const int first_end = (opt_presplit_samples > 0 && opt_presplit_samples < opt_split_samples) ? opt_presplit_samples : opt_split_samples;
+        const int first_end = (g_opt.presplit_samples > 0 && g_opt.presplit_samples < g_opt.split_samples) ? g_opt.presplit_samples : g_opt.split_samples;
         HIPCHK(hipMemsetAsync(s->d_tile_cost, 0, n_tiles * sizeof(unsigned int), stream));
         HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
         rt_frame_params p1 = fp;
         p1.sample_end = first_end; p1.state_out = s->d_state; p1.tile_cost = s->d_tile_cost;
-        rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, p1, grid, block, lds_bytes, stream);
-        HIPCHK(hipGetLastError());
+        HIPCHK(launch_render(kernel, lds_mode, s, p1, grid, block, lds_bytes, stream));
         // ---- part 1b: samples [S_a, S0), already with tiers ranked on the first S_a samples.  Part 1 is bound by the
         // chains of the dearest pixels run at an ordinary wave's pace; a short first look is enough to find most of them.
-        if (first_end < opt_split_samples) {
+        if (first_end < g_opt.split_samples) {
             rt_frame_params p2 = fp;
             dim3 grid2 = grid;
-            p2.sample_begin = first_end; p2.sample_end = opt_split_samples;
+            p2.sample_begin = first_end; p2.sample_end = g_opt.split_samples;
             p2.state_in = s->d_state; p2.state_out = s->d_state; p2.tile_cost = s->d_tile_cost;
             const rt_status st2 = rank_pixels(p2, grid2);
             if (st2 != RT_OK) return st2;
             HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
-            rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, p2, grid2, block, lds_bytes, stream);
-            HIPCHK(hipGetLastError());
+            HIPCHK(launch_render(kernel, lds_mode, s, p2, grid2, block, lds_bytes, stream));
         }
         // ---- part 2: samples [S0, ns), ranked on the first S0 samples
         split = true;
-        fp.state_in = s->d_state; fp.sample_begin = opt_split_samples;
+        fp.state_in = s->d_state; fp.sample_begin = g_opt.split_samples;
         const rt_status st3 = rank_pixels(fp, grid);
         if (st3 != RT_OK) return st3;
         out.workgroups = (int)grid.x;
@@ -684,9 +733,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     (void)split;
     out.reserved = (int32_t)fp.heavy_items;
     HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));   // the ray counter keeps part 1's rays
-    if (kernel == RT_KERNEL_WAVEFRONT) rt_launch_wavefront(lds_mode, s->tex_level, s->dev, fp, grid, block, lds_bytes, stream);
-    else rt_launch_render(kernel, lds_mode, s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, grid, block, lds_bytes, stream);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_render(kernel, lds_mode, s, fp, grid, block, lds_bytes, stream));
     HIPCHK(hipEventRecord(s->ev_stop, stream));
     s->frame_pending = true;
     s->pending_stream = stream;

@@ -8,10 +8,11 @@
 
 #define RT_PERSISTENT_THREADS 512
 #ifndef RT_PARKED_MIN_WAVES
-#define RT_PARKED_MIN_WAVES 4   // waves per SIMD the parked kernel is register-limited to allow
+#define RT_PARKED_MIN_WAVES 4   // waves per SIMD the lean staged kernel (spheres-only, solid / checker colours) is register-limited to allow
 #endif
 
-enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_PERSISTENT = 1, RT_KERNEL_PARKED = 2, RT_KERNEL_STAGED = 3, RT_KERNEL_WAVEFRONT = 4 };
+// kernel ids keep their round-1 numbers (1 = persistent and 2 = parked were the steps between 0 and 3; removed)
+enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_STAGED = 3, RT_KERNEL_WAVEFRONT = 4 };
 
 // A pixel parked at a sample boundary (split frames): XORWOW state, colour sum, rays traced so far.
 struct rt_pixel_state {
@@ -67,7 +68,6 @@ struct rt_frame_params {
     int32_t sparse_stride;                // staged kernel: in sparse mode only every sparse_stride-th lane takes a pixel
     int32_t steps_per_trip;               // persistent kernel: node visits between ballots
     int32_t shade_threshold;              // persistent kernel: waiting lanes that trigger shading
-    int32_t leaf_threshold;               // parked kernel: parked lanes that trigger the leaf pass
     int32_t box_threshold, medium_threshold;   // staged kernel, general scenes: parked box/instance and medium lanes that trigger their leaf tests
     int32_t diel_threshold;               // staged kernel: dielectric hits that trigger their stage
     int32_t newpath_threshold;            // staged kernel: ended paths that trigger the new-path stage
@@ -78,8 +78,21 @@ struct rt_frame_params {
 
 void rt_launch_collect_heavy(const rt_pixel_state* state, unsigned int n_pixels, unsigned int threshold, unsigned long long* list,
                              unsigned int capacity, unsigned int* count, hipStream_t st);
-void rt_launch_wavefront(int lds_mode, int tex_level, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block,
-                         size_t lds_bytes, hipStream_t stream);
 #define RT_WF_BYTES_PER_SLOT (31 * 4 + 5 * 2)   /* 20 float + 11 int arrays, 5 u16 lists */
-void rt_launch_render(int kernel, int lds_mode, bool spheres_only, int tex_level, bool need_uv, const rt_scene_dev& sd,
-                      const rt_frame_params& fp, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream);
+
+// Launchers, one per translation unit (each returns the launch's hipError_t, including a failed
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize)).  tex_level: 0 = every material colour is inline, 1 = solid +
+// checker textures, 2 = noise / image / noodle / felt / uv-offset textures too (Perlin noise and the sphere-uv
+// transcendentals cost ~100 VGPRs, so scenes without them -- the headline random scene -- get leaner code).
+hipError_t rt_launch_pixel(bool spheres_only, int tex_level, bool need_uv, const rt_scene_dev& sd, const rt_frame_params& fp,
+                           dim3 grid, dim3 block, hipStream_t stream);
+hipError_t rt_launch_staged_spheres(int tex_level, int lds_mode, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid,
+                                    dim3 block, size_t lds, hipStream_t st);
+hipError_t rt_launch_staged_spheres_tex(int lds_mode, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block,
+                                        size_t lds, hipStream_t st);
+hipError_t rt_launch_staged_general(int lds_mode, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block,
+                                    size_t lds, hipStream_t st);
+hipError_t rt_launch_staged_general_tex(int lds_mode, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block,
+                                        size_t lds, hipStream_t st);
+hipError_t rt_launch_wavefront(int lds_mode, int tex_level, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block,
+                               size_t lds_bytes, hipStream_t stream);

@@ -1,0 +1,71 @@
+// rt_kernel_pixel.hip -- kernel 0 ("pixel"), see below.
+#include "rt_device_funcs.h"
+
+// =============================================================================
+// Kernel A ("pixel"): the reference's own loop nest, one lane per pixel, one
+// 8x8 tile per wave.  Kept as the simple form the persistent kernel is checked
+// against on the GPU, and as the A/B baseline for the scheduling work.
+// =============================================================================
+template <bool SPHERES_ONLY, int TEX, bool NEED_UV, int LDS_MODE>
+__global__ void __launch_bounds__(256) rt_render_pixel_kernel(rt_scene_dev sd, rt_frame_params fp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const SceneView sc = stage_scene<LDS_MODE>(sd, lds);
+
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    int i, lrow;
+    unsigned long long rays = 0;
+    if (w < fp.work_items && work_to_pixel(fp, w, i, lrow)) {
+        const int j = local_to_global_row(fp, lrow);
+        rt_xorwow g;
+        rt_xorwow_seed(g, fp.seed_base + (uint64_t)(j * fp.nx + i));   // render_init, main.cu:101-104
+        f3 col = mk3(0, 0, 0);
+        for (int s = 0; s < fp.ns; ++s) {
+            const float u = ((float)i + rt_xorwow_uniform(g)) / (float)fp.nx;
+            const float v = ((float)j + rt_xorwow_uniform(g)) / (float)fp.ny;
+            Ray cur = camera_get_ray(sd.camera, u, v, g);
+            f3 throughput = mk3(1, 1, 1), radiance = mk3(0, 0, 0);
+            for (int bounce = 0; bounce < 50; ++bounce) {
+                HitInfo h;
+                ++rays;
+                if (!trace<SPHERES_ONLY>(sc, cur, h)) {
+                    radiance = fma3(throughput, miss_color(fp, cur), radiance);
+                    break;
+                }
+                const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, h);
+                f3 emitted, attenuation;
+                Ray scattered;
+                const bool go_on = shade<TEX>(sc, cur, rec, g, emitted, attenuation, scattered);
+                radiance = fma3(throughput, emitted, radiance);
+                if (!go_on) break;
+                throughput = throughput * attenuation;
+                cur = scattered;
+            }
+            col = col + radiance;
+        }
+        store_pixel(fp, i, lrow, col);
+    }
+    // one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(fp.ray_counter, rays);
+}
+
+// Kernel 0 is the GPU-side cross-check of the staged kernel (tests) and the A/B baseline; it reads the scene through
+// L1/L2 (no LDS staging), which is all its role needs.
+namespace {
+template <bool SO, int TX, bool UV>
+hipError_t launch_pixel(const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block, hipStream_t st) {
+    hipLaunchKernelGGL((rt_render_pixel_kernel<SO, TX, UV, 0>), grid, block, 0, st, sd, fp);
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t rt_launch_pixel(bool spheres_only, int tex_level, bool need_uv, const rt_scene_dev& sd, const rt_frame_params& fp,
+                           dim3 grid, dim3 block, hipStream_t stream) {
+    if (spheres_only) {
+        if (tex_level == 0) return launch_pixel<true, 0, false>(sd, fp, grid, block, stream);
+        if (tex_level == 1) return launch_pixel<true, 1, false>(sd, fp, grid, block, stream);
+        return launch_pixel<true, 2, true>(sd, fp, grid, block, stream);
+    }
+    if (tex_level <= 1 && !need_uv) return launch_pixel<false, 1, false>(sd, fp, grid, block, stream);
+    return launch_pixel<false, 2, true>(sd, fp, grid, block, stream);
+}

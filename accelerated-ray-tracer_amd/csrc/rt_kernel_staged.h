@@ -1,0 +1,443 @@
+// rt_kernel_staged.h -- kernel 3 ("staged"), the kernel that ships; instantiated by rt_staged_*.hip.
+#pragma once
+#include "rt_device_funcs.h"
+
+// =============================================================================
+// Kernel D ("staged"): kernel C with the shading block cut into stages.
+//
+// Counters for kernel C (profiles/r01_bench_n1_parked_summary.txt, pmcsweep) put
+// ~60 % of all issued VALU instructions in the shading block: ~1500
+// instructions covering every material, the dielectric path, pixel
+// finalisation and camera-ray generation, executed for ~24 waiting lanes of
+// which each needs a fraction.  A microbenchmark (tools/ubench/valu_rate.hip)
+// shows the SIMDs are close to issue-bound at ~3-4 cycles per VALU
+// wave-instruction, so instructions issued for idle lanes are the cost.
+//
+// Here a lane's state is encoded in `node`:
+//   0 <= node < n      walking the BVH (next box test)
+//   node < 0           parked at a leaf; ~node is where the walk resumes
+//   node == n + 0      traversal finished, hit/miss not yet classified
+//   node == n + 1      path ended: needs accumulate + next sample / pixel + camera ray
+//   node == n + 2      dielectric hit waiting for the (rare, long) dielectric stage
+//   node == n + 3      new ray ready, needs per-ray setup (1/d etc.)
+//   node == n + 4      no more work
+// and each stage runs when a ballot finds enough lanes for it, or when no lane
+// can walk any more.  Lambertian, metal and isotropic share one
+// random_in_unit_sphere loop.  Stages only re-order work between lanes: every
+// pixel still draws its own XORWOW stream in the reference's order.
+// =============================================================================
+// Diagnostic build only (-DRT_DIAG): per-stage execution counts, written to fp.diag (never to an output).
+#ifdef RT_DIAG
+#define DIAG_ADD(slot, value) do { const unsigned long long v_ = (unsigned long long)(value); if ((threadIdx.x & 63) == 0) diag_local[slot] += v_; } while (0)
+#else
+#define DIAG_ADD(slot, value) do { } while (0)
+#endif
+
+template <bool SPHERES_ONLY, int TEX, bool NEED_UV, int LDS_MODE>
+__global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 2) ? RT_PARKED_MIN_WAVES : 2) rt_render_staged_kernel(rt_scene_dev sd, rt_frame_params fp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef RT_DIAG
+    unsigned long long diag_local[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const SceneView sc = stage_scene<LDS_MODE>(sd, lds);
+    const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
+    const int n_nodes = sc.n_nodes;
+    const int ST_DONE = n_nodes, ST_NEWPATH = n_nodes + 1, ST_DIEL = n_nodes + 2, ST_SETUP = n_nodes + 3, ST_DEAD = n_nodes + 4;
+    const float tmin = 0.001f;
+
+    rt_xorwow g = {0, 0, 0, 0, 0, 0};
+    int px_i = 0, px_lrow = 0, px_j = 0, sample = 0, bounce = 0;
+    f3 col = mk3(0, 0, 0), throughput = mk3(1, 1, 1), radiance = mk3(0, 0, 0);
+    Ray cur; cur.o = mk3(0, 0, 0); cur.d = mk3(0, 0, 1); cur.tm = 0.f;
+    f3 inv = mk3(1, 1, 1);
+    HitInfo best; best.t = FLT_MAX; best.prim = -1; best.inst = -1;
+    int node = ST_NEWPATH;       // every lane starts by asking for a pixel
+    int32_t parked = -1;
+    bool have_pixel = false, first = true, finite_inv = true;
+    unsigned int rays = 0, rays_at_pixel_start = 0;
+    // Sparse mode (see rt_abi.hip, "heavy tiles"): the first fp.sparse_wgs workgroups start by serving the queue of the
+    // few dearest tiles with only every fp.sparse_stride-th lane, because a lane's rays advance ~2.5x faster in a wave
+    // with few live lanes and those pixels' sequential chains bound the frame time.  When that queue is drained and the
+    // wave's own heavy pixels are finished it becomes an ordinary wave.  Wave-uniform.
+    bool sparse = (int)blockIdx.x < fp.sparse_wgs;
+    // Tier-1 waves hold ONE pixel each -- the dearest pixels of the frame, whose sequential chains bound the frame time.
+    // With a single live lane the state machine below is pure overhead, so they run the reference's plain loop nest
+    // (as kernel A does) on pixels parked by part 1, one after another, and only then join the ordinary waves.
+    // Tier-0 workgroups (spheres-only scenes) go one step further for the very dearest pixels: the whole workgroup holds
+    // ONE pixel and every ray is traced by all its threads at once (trace_group()), which cuts the time per ray -- and
+    // with it the sequential chain that bounds the frame and every multi-GPU partition of it -- several times over.
+    const bool tier0 = SPHERES_ONLY && LDS_MODE == 2 && (int)blockIdx.x < fp.tier0_wgs && fp.state_in != nullptr;   // workgroup-uniform
+    const bool tier1 = sparse && !tier0 && (int)blockIdx.x < fp.tier0_wgs + fp.tier1_wgs && fp.state_in != nullptr;
+    if (tier0 || tier1) {
+        __builtin_amdgcn_s_setprio(3);
+        unsigned int* t0_scratch = reinterpret_cast<unsigned int*>(lds + fp.tier0_lds_offset);
+        unsigned long long* t0_slots = reinterpret_cast<unsigned long long*>(t0_scratch + 4);   // [2][16]
+        unsigned int* t0_leaves = t0_scratch + 4 + 64;
+        int t0_n_leaves = 0, t0_parity = 0;
+        if (tier0) {
+            if (threadIdx.x == 0) t0_scratch[0] = 0u;
+            __syncthreads();
+            for (int k = (int)threadIdx.x; k < n_nodes; k += (int)blockDim.x)
+                if (sc.nodes[k].prim >= 0) t0_leaves[atomicAdd(&t0_scratch[0], 1u)] = (unsigned int)k;
+            __syncthreads();
+            t0_n_leaves = (int)t0_scratch[0];
+        }
+        // every lane of the wave (tier 1) / thread of the workgroup (tier 0) carries the same pixel and computes the same
+        // values; only the traversal is shared out
+        for (;;) {
+            uint32_t idx = 0;
+            if (tier0) {
+                if (threadIdx.x == 0) t0_scratch[1] = atomicAdd(fp.work_counter + 3, 1u);
+                __syncthreads();
+                idx = t0_scratch[1];
+                __syncthreads();
+                if (idx >= fp.tier0_items) break;
+            } else {
+                if ((threadIdx.x & 63) == 0) idx = atomicAdd(fp.work_counter + 2, 1u);
+                idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+                if (idx >= fp.tier1_items) break;
+                idx += fp.tier0_items;
+            }
+            const uint32_t pix = fp.heavy_pixels[idx];
+            const int lrow = (int)(pix / (uint32_t)fp.nx), i = (int)(pix - (uint32_t)lrow * (uint32_t)fp.nx);
+            const int j = local_to_global_row(fp, lrow);
+            const rt_pixel_state st = fp.state_in[pix];
+            rt_xorwow pg;
+            pg.v0 = st.rng[0]; pg.v1 = st.rng[1]; pg.v2 = st.rng[2]; pg.v3 = st.rng[3]; pg.v4 = st.rng[4]; pg.d = st.rng[5];
+            f3 pcol = mk3(st.col[0], st.col[1], st.col[2]);
+            unsigned int pixel_rays = 0;
+            for (int sidx = fp.sample_begin; sidx < fp.sample_end; ++sidx) {                 // main.cu:119-125
+                const float u = ((float)i + rt_xorwow_uniform(pg)) / (float)fp.nx;
+                const float v = ((float)j + rt_xorwow_uniform(pg)) / (float)fp.ny;
+                Ray r = camera_get_ray(sd.camera, u, v, pg);
+                f3 thr = mk3(1, 1, 1), rad = mk3(0, 0, 0);
+                for (int depth = 0; depth < 50; ++depth) {                                   // main.cu:54-84
+                    HitInfo h;
+                    ++pixel_rays;
+#ifdef RT_DIAG
+                    const unsigned long long dg0 = __builtin_readcyclecounter();
+#endif
+                    const bool hit = tier0 ? trace_group(sc, r, h, t0_leaves, t0_n_leaves, t0_slots, t0_parity) : trace_wide<SPHERES_ONLY>(sc, r, h);
+#ifdef RT_DIAG
+                    const unsigned long long dg1 = __builtin_readcyclecounter();
+                    if (threadIdx.x == 0) { diag_local[15] += 1; diag_local[14] += dg1 - dg0; }   // slots 14/15: tier loops only
+#endif
+                    if (!hit) { rad = fma3(thr, miss_color(fp, r), rad); break; }
+                    const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, r, h);
+                    f3 emitted, attenuation;
+                    Ray scattered;
+                    const bool go_on = shade<TEX>(sc, r, rec, pg, emitted, attenuation, scattered);
+
+                    rad = fma3(thr, emitted, rad);
+                    if (!go_on) break;
+                    thr = thr * attenuation;
+                    r = scattered;
+                }
+                pcol = pcol + rad;
+            }
+            if (tier0 ? threadIdx.x == 0 : (threadIdx.x & 63) == 0) {
+                if (fp.state_out) {   // a middle part of a split frame: park the pixel again
+                    rt_pixel_state so;
+                    so.rng[0] = pg.v0; so.rng[1] = pg.v1; so.rng[2] = pg.v2; so.rng[3] = pg.v3; so.rng[4] = pg.v4; so.rng[5] = pg.d;
+                    so.col[0] = pcol.x; so.col[1] = pcol.y; so.col[2] = pcol.z; so.cost = fp.state_in[pix].cost + pixel_rays;
+                    fp.state_out[pix] = so;
+                    atomicAdd(&fp.tile_cost[(lrow >> 3) * fp.tiles_x + (i >> 3)], pixel_rays);
+                } else {
+                    store_pixel(fp, i, lrow, pcol);
+                }
+                rays += pixel_rays;
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        sparse = false;   // queue drained: this wave / workgroup becomes ordinary
+    }
+    // A sparse wave's few lanes are on the frame's critical path: let it win instruction-issue arbitration against the
+    // three ordinary waves sharing its SIMD (priority outranks age, MI355X_MICROARCH.md "Two waves per SIMD").
+    if (sparse && fp.sparse_priority > 0) {
+        if (fp.sparse_priority == 1) __builtin_amdgcn_s_setprio(1);
+        else if (fp.sparse_priority == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
+
+    for (;;) {
+        DIAG_ADD(0, 1);
+        // ---------------- stage A: node steps
+        if (__ballot(!finite_inv && (unsigned)node < (unsigned)n_nodes) == 0ull) {
+            const int trip_steps = sparse ? 2 * fp.steps_per_trip : fp.steps_per_trip;
+            for (int step = 0; step < trip_steps; ++step) {
+                // nobody left walking (all parked or finished): end the trip now -- this is what keeps the latency of
+                // a wave's last few live lanes near one node step per step (end of frame, small multi-GPU partitions)
+                if (__ballot((unsigned)node < (unsigned)n_nodes) == 0ull) break;
+                DIAG_ADD(1, 1); DIAG_ADD(2, __popcll(__ballot((unsigned)node < (unsigned)n_nodes)));
+                if ((unsigned)node < (unsigned)n_nodes) {
+                    const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
+                    const bool pass = slab_test_finite(a, b, cur.o, inv, tmin, best.t);
+                    const int32_t prim = __float_as_int(b.w);
+                    const int skip = __float_as_int(a.w);
+                    const bool at_leaf = pass && prim >= 0;
+                    const int next = (pass && prim < 0) ? node + 1 : skip;
+                    parked = at_leaf ? prim : parked;
+                    node = at_leaf ? ~next : next;
+                }
+            }
+        } else {   // a lane's ray has a zero direction component: the reference's own slab form for this trip
+            for (int step = 0; step < fp.steps_per_trip; ++step) {
+                if (__ballot((unsigned)node < (unsigned)n_nodes) == 0ull) break;
+                if ((unsigned)node < (unsigned)n_nodes) {
+                    const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
+                    const bool pass = slab_test(a, b, cur.o, inv, tmin, best.t);
+                    const int32_t prim = __float_as_int(b.w);
+                    const int skip = __float_as_int(a.w);
+                    const bool at_leaf = pass && prim >= 0;
+                    const int next = (pass && prim < 0) ? node + 1 : skip;
+                    parked = at_leaf ? prim : parked;
+                    node = at_leaf ? ~next : next;
+                }
+            }
+        }
+        // ---------------- stage B: leaf pass for parked lanes
+        DIAG_ADD(3, __ballot(node < 0) != 0ull); DIAG_ADD(4, __popcll(__ballot(node < 0)));
+        if (SPHERES_ONLY) {
+            if (node < 0) {
+                leaf_test<true>(sc, parked, cur, tmin, best);
+                parked = -1;
+                node = ~node;
+            }
+        } else {
+            // General scenes: spheres and quads are served every trip; boxes / instances (six quad tests, a transform)
+            // and media (two boundary tests, a private XORWOW, a logarithm) are long, so their lanes stay parked until a
+            // ballot finds enough of them -- or nobody is left who could step.
+            const int kind = node < 0 ? RT_PRIM_KIND(parked) : -1;
+            if (kind == RT_PRIM_SPHERE || kind == RT_PRIM_QUAD) {
+                float t;
+                const bool hit = kind == RT_PRIM_SPHERE ? sphere_test(sc.spheres[RT_PRIM_INDEX(parked)], cur, tmin, best.t, t)
+                                                        : quad_test(sc.quads[RT_PRIM_INDEX(parked)], cur, tmin, best.t, t);
+                if (hit) { best.t = t; best.prim = parked; best.inst = -1; }
+                parked = -1;
+                node = ~node;
+            }
+            const bool nobody_steps = __ballot((unsigned)node < (unsigned)n_nodes) == 0ull;
+            const int live_b = __popcll(__ballot(node != ST_DEAD));
+            const unsigned long long box_mask = __ballot(kind == RT_PRIM_BOX || kind == RT_PRIM_INSTANCE);
+            if (box_mask != 0ull && (nobody_steps || __popcll(box_mask) >= 1 + ((fp.box_threshold - 1) * live_b >> 6))) {
+                if (kind == RT_PRIM_BOX || kind == RT_PRIM_INSTANCE) {
+                    float t;
+                    int32_t leaf = parked, inst = -1;
+                    if (solid_test(sc, parked, cur, tmin, best.t, t, leaf, inst)) { best.t = t; best.prim = leaf; best.inst = inst; }
+                    parked = -1;
+                    node = ~node;
+                }
+            }
+            const unsigned long long med_mask = __ballot(kind == RT_PRIM_MEDIUM);
+            if (med_mask != 0ull && (nobody_steps || __popcll(med_mask) >= 1 + ((fp.medium_threshold - 1) * live_b >> 6))) {
+                if (kind == RT_PRIM_MEDIUM) {
+                    float t;
+                    if (medium_test(sc, sc.media[RT_PRIM_INDEX(parked)], cur, tmin, best.t, t)) { best.t = t; best.prim = parked; best.inst = -1; }
+                    parked = -1;
+                    node = ~node;
+                }
+            }
+        }
+        // a finished walk that hit nothing (main.cu:57-68) needs no stage: add the background and end the path now
+        if (node == ST_DONE && best.prim < 0) {
+            radiance = fma3(throughput, miss_color(fp, cur), radiance);
+            node = ST_NEWPATH;
+        }
+        const unsigned long long walking = __ballot(node < n_nodes);
+        const bool force = walking == 0ull;
+        const int n_done = __popcll(__ballot(node == ST_DONE));
+        bool ran_stage = false;
+        // The thresholds are fractions of the lanes that still have work: a wave whose lanes are running out of pixels
+        // (end of the frame, or a small row partition on a multi-GPU run) must not wait for 24 lanes it no longer has.
+        const int live = __popcll(__ballot(node != ST_DEAD));
+        const int shade_need = 1 + ((fp.shade_threshold - 1) * live >> 6);
+        const int diel_need = 1 + ((fp.diel_threshold - 1) * live >> 6);
+        const int newpath_need = 1 + ((fp.newpath_threshold - 1) * live >> 6);
+        const bool eager = sparse && fp.sparse_eager;     // sparse waves trade their own throughput for latency
+
+        // ---------------- stage C: classify + resolve + diffuse/metal/isotropic scatter
+        if (n_done > 0 && (n_done >= shade_need || force || eager)) {
+            ran_stage = true;
+            DIAG_ADD(5, 1); DIAG_ADD(6, n_done);
+            DIAG_ADD(11, __popcll(__ballot(node == ST_DONE && best.prim >= 0)));
+            if (node == ST_DONE) {
+                {
+                    const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, best);
+                    const rt_material m = sc.materials[rec.mat];
+                    if (m.kind == RT_MAT_DIELECTRIC) {
+                        if (sparse) {
+                            // a sparse wave's pixels are mostly glass: scatter here instead of queueing for stage D
+                            // (saves a second resolve_hit and a stage round trip on the frame's critical chain)
+                            const f3 dir = dielectric_direction(cur.d, rec.n, m.ior, g);
+                            ++bounce;
+                            if (bounce >= 50) node = ST_NEWPATH;
+                            else { cur.o = rec.p; cur.d = dir; node = ST_SETUP; }   // attenuation (1,1,1): throughput unchanged
+                        } else {
+                            node = ST_DIEL;
+                        }
+                    } else if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
+                        const f3 emitted = (TEX > 0 && m.tex >= 0) ? texture_value<TEX>(sc, m.tex, rec.u, rec.v, rec.p) : ld3(m.albedo);
+                        radiance = fma3(throughput, emitted, radiance);         // main.cu:71, scatter() false
+                        node = ST_NEWPATH;
+                    } else {
+                        // lambertian / metal / isotropic: one shared rejection loop (material.cuh:12-18)
+                        const f3 rs = random_in_unit_sphere(g);
+                        f3 dir, attenuation;
+                        bool go_on = true;
+                        if (m.kind == RT_MAT_METAL) {                       // material.cuh:99-109
+                            const f3 reflected = reflect(unit_vector(cur.d), rec.n);
+                            dir = fma3(m.fuzz, rs, reflected);
+                            attenuation = ld3(m.albedo);
+                            go_on = dot(dir, rec.n) > 0.0f;
+                        } else {
+                            if (m.kind == RT_MAT_LAMBERTIAN) {              // material.cuh:75-86
+                                const f3 target = (rec.p + rec.n) + rs;
+                                dir = target - rec.p;
+                            } else {                                        // isotropic, material.cuh:193-200
+                                dir = rs;
+                            }
+                            attenuation = (TEX > 0 && m.tex >= 0) ? texture_value<TEX>(sc, m.tex, rec.u, rec.v, rec.p) : ld3(m.albedo);
+                        }
+                        ++bounce;
+                        if (!go_on || bounce >= 50) node = ST_NEWPATH;      // main.cu:54,76-80
+                        else {
+                            throughput = throughput * attenuation;
+                            cur.o = rec.p; cur.d = dir;                     // time carried over
+                            node = ST_SETUP;
+                        }
+                    }
+                }
+            }
+        }
+        // ---------------- stage D: dielectric scatter (material.cuh:119-159)
+        {
+            const int n_diel = __popcll(__ballot(node == ST_DIEL));
+            if (n_diel > 0 && (n_diel >= diel_need || force || eager)) {
+                ran_stage = true;
+                DIAG_ADD(7, 1); DIAG_ADD(8, n_diel);
+                if (node == ST_DIEL) {
+                    const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, best);
+                    const f3 dir = dielectric_direction(cur.d, rec.n, sc.materials[rec.mat].ior, g);
+                    ++bounce;
+                    if (bounce >= 50) node = ST_NEWPATH;
+                    else { throughput = throughput * mk3(1.0f, 1.0f, 1.0f); cur.o = rec.p; cur.d = dir; node = ST_SETUP; }
+                }
+            }
+        }
+        // ---------------- stage E: path end -> next sample / next pixel -> camera ray (main.cu:119-132)
+        {
+            const int n_new = __popcll(__ballot(node == ST_NEWPATH));
+            if (n_new > 0 && (n_new >= newpath_need || force || eager)) {
+                ran_stage = true;
+                DIAG_ADD(9, 1); DIAG_ADD(10, n_new);
+                if (node == ST_NEWPATH) {
+                    if (!first) { col = col + radiance; ++sample; }
+                    first = false;
+                    bool alive = true;
+                    if (have_pixel && sample >= fp.sample_end) {
+                        if (fp.state_out) {
+                            // first part of a split frame: park the pixel at this sample boundary (no path is in flight
+                            // here, so the XORWOW state and the colour sum are the whole state) and record what it cost
+                            const unsigned int c = rays - rays_at_pixel_start;
+                            const size_t at = (size_t)px_lrow * fp.nx + px_i;
+                            rt_pixel_state st;
+                            st.rng[0] = g.v0; st.rng[1] = g.v1; st.rng[2] = g.v2; st.rng[3] = g.v3; st.rng[4] = g.v4; st.rng[5] = g.d;
+                            st.col[0] = col.x; st.col[1] = col.y; st.col[2] = col.z;
+                            st.cost = c + (fp.state_in ? fp.state_in[at].cost : 0u);   // a middle part adds to what the pixel cost before
+                            fp.state_out[at] = st;
+                            atomicAdd(&fp.tile_cost[(px_lrow >> 3) * fp.tiles_x + (px_i >> 3)], c);
+                        } else {
+                            store_pixel(fp, px_i, px_lrow, col);
+                        }
+                        have_pixel = false;
+                    }
+                    while (!have_pixel && alive) {
+                        bool ok;
+                        if (sparse) {
+                            // heavy list (sorted by descending cost): tier 1 = its first tier1_items entries
+                            // tier 2 of the heavy list (tier 1 is served by the plain loop at the top of the kernel)
+                            if (((threadIdx.x & 63) % (unsigned)fp.sparse_stride) != 0u) { alive = false; break; }
+                            const uint32_t at = fp.tier0_items + fp.tier1_items + atomicAdd(fp.work_counter + 1, 1u);
+                            if (at >= fp.heavy_items) { alive = false; break; }
+                            const uint32_t pix = fp.heavy_pixels[at];
+                            px_lrow = (int)(pix / (uint32_t)fp.nx); px_i = (int)(pix - (uint32_t)px_lrow * (uint32_t)fp.nx);
+                            ok = true;
+                        } else {
+                            const uint32_t w = atomicAdd(fp.work_counter, 1u);
+                            if (w >= fp.work_items) { alive = false; break; }
+                            ok = work_to_pixel(fp, w, px_i, px_lrow);
+                            // pixels in the heavy list belong to the sparse waves
+                            if (ok && fp.heavy_items && fp.state_in[(size_t)px_lrow * fp.nx + px_i].cost >= fp.heavy_threshold) ok = false;
+                        }
+                        if (ok) {
+                            px_j = local_to_global_row(fp, px_lrow);
+                            if (fp.state_in) {   // second part of a split frame: pick the pixel up where the first part left it
+                                const rt_pixel_state st = fp.state_in[(size_t)px_lrow * fp.nx + px_i];
+                                g.v0 = st.rng[0]; g.v1 = st.rng[1]; g.v2 = st.rng[2]; g.v3 = st.rng[3]; g.v4 = st.rng[4]; g.d = st.rng[5];
+                                col = mk3(st.col[0], st.col[1], st.col[2]);
+                            } else {
+                                rt_xorwow_seed(g, fp.seed_base + (uint64_t)(px_j * fp.nx + px_i));
+                                col = mk3(0, 0, 0);
+                            }
+                            sample = fp.sample_begin; have_pixel = true;
+                            rays_at_pixel_start = rays;
+                        }
+                    }
+                    if (alive) {
+                        const float u = ((float)px_i + rt_xorwow_uniform(g)) / (float)fp.nx;
+                        const float v = ((float)px_j + rt_xorwow_uniform(g)) / (float)fp.ny;
+                        cur = camera_get_ray(sd.camera, u, v, g);
+                        throughput = mk3(1, 1, 1); radiance = mk3(0, 0, 0); bounce = 0;
+                        node = ST_SETUP;
+                    } else {
+                        node = ST_DEAD;
+                    }
+                }
+            }
+        }
+        // ---------------- stage F: per-ray setup
+        if (ran_stage) {
+            DIAG_ADD(12, 1); DIAG_ADD(13, __popcll(__ballot(node == ST_SETUP)));
+            if (node == ST_SETUP) {
+                inv = mk3(1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z);
+                finite_inv = inv_is_finite(inv);
+                best.t = FLT_MAX; best.prim = -1; best.inst = -1;
+                node = n_nodes > 0 ? 0 : ST_DONE;
+                ++rays;
+            }
+        } else if (force) {
+            // nothing walking, nothing waiting: every lane is ST_DEAD
+            if (!sparse) break;
+            sparse = false;                         // heavy queue drained and our heavy pixels done: become an ordinary wave
+            __builtin_amdgcn_s_setprio(0);
+            node = ST_NEWPATH; first = true; have_pixel = false;
+        }
+    }
+    unsigned long long r64 = rays;
+    for (int off = 32; off > 0; off >>= 1) r64 += __shfl_down(r64, off, 64);
+    if ((threadIdx.x & 63) == 0 && r64) atomicAdd(fp.ray_counter, r64);
+#ifdef RT_DIAG
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 16; ++k) atomicAdd(fp.ray_counter + 1 + k, diag_local[k]);
+#endif
+}
+
+// One specialisation family per translation unit (rt_staged_*.hip), so that the families compile in parallel.
+template <bool SO, int TX, bool UV>
+static hipError_t rt_launch_staged_family(int lds_mode, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block,
+                                          size_t lds, hipStream_t st) {
+#define RT_STAGED_LAUNCH(LM)                                                                                              \
+    do {                                                                                                                  \
+        if (lds > 65536) {                                                                                                \
+            const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_render_staged_kernel<SO, TX, UV, LM>), \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+            if (e_ != hipSuccess) return e_;                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((rt_render_staged_kernel<SO, TX, UV, LM>), grid, block, lds, st, sd, fp);                      \
+        return hipGetLastError();                                                                                         \
+    } while (0)
+    if (lds_mode >= 3) RT_STAGED_LAUNCH(3);
+    if (lds_mode == 2) RT_STAGED_LAUNCH(2);
+    if (lds_mode == 1) RT_STAGED_LAUNCH(1);
+    RT_STAGED_LAUNCH(0);
+#undef RT_STAGED_LAUNCH
+}

@@ -212,8 +212,10 @@ rt_status rt_render(rt_scene* scene, const rt_frame_desc* f, float* fb, int fb_o
 rt_status rt_frame_finish(rt_scene* scene, rt_stats* stats);
 
 /* Tuning knobs (for A/B measurements; defaults are what ships).  Unknown keys
- * return RT_ERR_INVALID. */
+ * return RT_ERR_INVALID.  The knobs are process-wide; rt_reset_options()
+ * restores every one of them to the shipped default.  None changes a pixel. */
 rt_status rt_set_option(const char* key, int value);
+rt_status rt_reset_options(void);
 
 #ifdef __cplusplus
 }

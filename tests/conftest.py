@@ -38,6 +38,17 @@ def gpu(art):
     return art
 
 
+@pytest.fixture(autouse=True)
+def _shipped_options():
+    """The scheduling knobs (rt_set_option) are process-wide: every test starts from, and leaves behind, the shipped defaults."""
+    import accelerated_ray_tracer_amd as art
+    if art._rt is not None:
+        art.reset_options()
+    yield
+    if art._rt is not None:
+        art.reset_options()
+
+
 @pytest.fixture(scope="session")
 def earth(art):
     return art.default_texture()

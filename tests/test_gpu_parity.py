@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-4
-KERNELS = [0, 1, 2, 3, 4]   # pixel, persistent, parked, staged (the default), wavefront (experimental; spheres-only scenes)
+KERNELS = [0, 3, 4]   # pixel (the reference's loop nest, GPU-side cross-check), staged (the default), wavefront (experimental; spheres-only scenes)
 
 
 def assert_frames_equal(got, ref, what=""):
@@ -30,19 +30,20 @@ DEFAULT_KERNEL = 3
 
 
 def render(art, hs, kernel=DEFAULT_KERNEL, opts=None, **frame_kw):
+    """One frame through the C ABI with the shipped defaults (rt_reset_options) plus `opts`."""
+    art.reset_options()
     art.set_option("kernel", kernel)
-    defaults = {"lds_mode": -1, "steps_per_trip": 12, "shade_threshold": 32, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512,
-                "diel_threshold": 2, "box_threshold": 8, "medium_threshold": 16, "newpath_threshold": 24, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1,
-                "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 40, "heavy_max_tiles": 0, "tier1_pixels": 256, "tier1_factor_x10": 70, "split_samples": 32, "presplit_samples": 8, "tier0_auto": 0, "tier0_pixels": 128, "tier0_factor_x10": 70, "sparse_wg_percent": 35, "sparse_priority": 3,
-                "sparse_eager": 0}
-    defaults.update(opts or {})
-    for k, v in defaults.items():
+    opts = dict(opts or {})
+    if "tier0_auto" not in opts and any(k.startswith(("tier0_", "tier1_", "heavy_", "sparse_wg")) for k in opts):
+        opts["tier0_auto"] = 0          # hand-set tier sizes only apply with the automatic sizing off
+    for k, v in opts.items():
         art.set_option(k, v)
     ds = art.DeviceScene(hs)
     try:
         fb, st = ds.render(hs.frame(**frame_kw))
     finally:
         ds.close()
+        art.reset_options()
     return fb, st
 
 
@@ -145,17 +146,14 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
                 (3, {"threads": 64, "wg_per_cu": 8, "shade_threshold": 40, "newpath_threshold": 3}),
                 (4, {}), (4, {"wf_threads": 1024, "lds_mode": 1}), (4, {"wf_threads": 256, "wf_slots": 384, "wf_wg_per_cu": 3, "lds_mode": 0, "wf_pause_lanes": 64}),
                 (4, {"wf_pause_lanes": 1, "steps_per_trip": 3}),
-                (1, {}), (2, {}), (2, {"lds_mode": 0}), (2, {"lds_mode": 1}), (1, {"lds_mode": 0}), (0, {"lds_mode": 0}),
-                (2, {"steps_per_trip": 1}), (2, {"steps_per_trip": 13, "leaf_threshold": 40}), (2, {"shade_threshold": 1}),
-                (2, {"shade_threshold": 64, "leaf_threshold": 64}), (2, {"threads": 256, "wg_per_cu": 3}), (2, {"threads": 64, "wg_per_cu": 8}),
-                (1, {"threads": 128, "steps_per_trip": 3, "shade_threshold": 7})]
+                (0, {"lds_mode": 0})]
     for kernel, opts in variants:
         fb, st = render(gpu, hs, kernel, opts, ns=6)
         assert st.rays == st0.rays, (kernel, opts)
         assert np.array_equal(fb.view(np.uint32), base.view(np.uint32)), (kernel, opts)
     hs2 = gpu.HostScene("cornell_smoke", 48, 48)
     base2, _ = render(gpu, hs2, 0, ns=4)
-    for kernel, opts in [(3, {}), (3, {"lds_mode": 0, "diel_threshold": 1}), (2, {}), (2, {"lds_mode": 0}), (1, {"lds_mode": 1}), (2, {"steps_per_trip": 2, "shade_threshold": 60})]:
+    for kernel, opts in [(3, {}), (3, {"lds_mode": 0, "diel_threshold": 1}), (3, {"lds_mode": 1, "box_threshold": 1, "medium_threshold": 1}), (3, {"steps_per_trip": 2, "shade_threshold": 60, "box_threshold": 64, "medium_threshold": 64})]:
         fb, _ = render(gpu, hs2, kernel, opts, ns=4)
         assert np.array_equal(fb.view(np.uint32), base2.view(np.uint32)), (kernel, opts)
 

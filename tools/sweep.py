@@ -13,7 +13,6 @@ ap.add_argument("--scene", default="random_scene"); ap.add_argument("--nx", type
 ap.add_argument("--ns", type=int, default=50); ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("cfgs", nargs="+")
 a = ap.parse_args()
-DEFAULTS = {"kernel": 3, "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 40, "heavy_max_tiles": 0, "tier1_pixels": 256, "tier1_factor_x10": 70, "split_samples": 32, "presplit_samples": 8, "tier0_auto": 1, "tier0_pixels": 128, "tier0_factor_x10": 70, "sparse_wg_percent": 35, "sparse_eager": 0, "sparse_priority": 3, "wf_slots": 0, "wf_pause_lanes": 32, "wf_threads": 512, "wf_wg_per_cu": 1, "diel_threshold": 2, "box_threshold": 8, "medium_threshold": 16, "newpath_threshold": 24, "lds_mode": -1, "steps_per_trip": 12, "shade_threshold": 32, "leaf_threshold": 1, "wg_per_cu": 2, "threads": 512}
 art.init(0)
 img, iw, ih = art.default_texture(a.scene)
 hs = art.HostScene(a.scene, a.nx, a.ny, img, iw, ih)
@@ -23,10 +22,9 @@ buf = torch.zeros((a.ny, a.nx, 3), dtype=torch.float32, device="cuda")
 times = {c: [] for c in a.cfgs}; digest = {}; rays = {}; variant = {}
 for rnd in range(a.rounds):
     for c in a.cfgs:
-        opts = dict(DEFAULTS)
+        art.reset_options()
         for kv in c.split(","):
-            if kv: k, v = kv.split("="); opts[k] = int(v)
-        for k, v in opts.items(): art.set_option(k, v)
+            if kv: k, v = kv.split("="); art.set_option(k, int(v))
         buf.zero_()
         _, st = ds.render(frame, out=buf.data_ptr(), blocking=True)
         times[c].append(st.ms_render); rays[c] = st.rays; variant[c] = (st.kernel_variant, st.workgroups, st.threads_per_group, st.lds_bytes, st.reserved)
