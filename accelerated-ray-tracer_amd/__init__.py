@@ -71,7 +71,7 @@ MATERIAL_DTYPE = np.dtype([("kind", "<i4"), ("tex", "<i4"), ("fuzz", "<f4"), ("i
 # every symbol include/rt_abi.h declares
 RT_ABI_SYMBOLS = ["rt_init", "rt_shutdown", "rt_strerror", "rt_last_hip_error", "rt_last_error_detail", "rt_scene_create",
                   "rt_scene_destroy", "rt_frame_local_rows", "rt_local_to_global_row", "rt_render", "rt_frame_finish",
-                  "rt_set_option", "rt_reset_options"]
+                  "rt_set_option", "rt_reset_options", "rt_scene_walk_info"]
 
 _rt = None
 _host = None
@@ -128,6 +128,7 @@ def rt_lib():
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RtFrameDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(RtStats)]
         L.rt_frame_finish.argtypes = [C.c_void_p, C.POINTER(RtStats)]
         L.rt_set_option.argtypes = [C.c_char_p, C.c_int]
+        L.rt_scene_walk_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _rt = L
     return _rt
 
@@ -273,6 +274,12 @@ class DeviceScene:
             return out, stats
         _check(L.rt_render(self._p, C.byref(frame), C.c_void_p(int(out)), 1, stream, 1 if blocking else 0, C.byref(stats)), "rt_render")
         return None, stats
+
+    def walk_info(self) -> dict:
+        """Node counts of the reference tree / the walk array and expected box tests per ray on the calibration frame."""
+        a, b, x, y = C.c_int32(0), C.c_int32(0), C.c_double(0), C.c_double(0)
+        _check(rt_lib().rt_scene_walk_info(self._p, C.byref(a), C.byref(b), C.byref(x), C.byref(y)), "rt_scene_walk_info")
+        return {"nodes_reference": a.value, "nodes_walked": b.value, "tests_before": x.value, "tests_after": y.value}
 
     def finish(self) -> RtStats:
         stats = RtStats()

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -38,6 +39,7 @@ struct rt_options {
     int shade_threshold = 32;
     int wg_per_cu = 2;
     int threads = RT_PERSISTENT_THREADS;
+    int leaf_threshold = 8;     // lanes with an object test due that trigger the leaf pass (they keep walking meanwhile)
     int diel_threshold = 2;
     int box_threshold = 8;
     int medium_threshold = 16;
@@ -55,6 +57,8 @@ struct rt_options {
     int sparse_priority = 3;
     int sparse_eager = 0;
     int sparse_wg_percent = 35;   // at most this share of the workgroups starts in sparse mode
+    int bvh_collapse = 2;        // walk array (rt_scene_create): 0 = the reference's tree as is, 1 = interior nodes that do not pay
+                                 // removed, decided from box surface areas, 2 = decided from pass counts measured on a small frame
     int lpt = 1;                 // cost prepass + longest-first tile order (staged kernel, ns >= 2 * split_samples)
     int wf_slots = 0;            // 0 = as many as fit in LDS (<= 1024)
     int wf_pause_lanes = 32;
@@ -102,7 +106,8 @@ struct rt_scene {
     std::vector<void*> allocs;
     bool spheres_only = false, need_uv = false;
     int tex_level = 0;
-    size_t node_bytes = 0, sphere_bytes = 0, shade_bytes = 0;   // shade_bytes: materials + textures
+    size_t node_bytes = 0, sphere_bytes = 0, shade_bytes = 0;   // node_bytes: the walk array; shade_bytes: materials + textures
+    double walk_tests_before = 0, walk_tests_after = 0;          // expected box tests per calibration ray, reference tree / walk array
     // per-frame resources
     unsigned long long* d_ray_counter = nullptr;
     unsigned int* d_work_counter = nullptr;
@@ -224,6 +229,116 @@ rt_status validate(const rt_scene_desc* d, bool& spheres_only, int& tex_level, b
 
 }  // namespace
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// "Collapse": which interior nodes of the reference's tree are worth testing.
+//
+// bvh_node::hit (bvh.cuh:95-106) reaches an object iff every ancestor box and the object's own box (its single-object
+// node, bvh.cuh:38-43) pass against the closest hit so far.  The slab test (aabb.cuh:45-61) is monotone in the box (a
+// box containing another is entered no later and left no earlier, rounding included: the same subtract-multiply on
+// ordered operands; a NaN from 0 * inf leaves a limit unconstrained for parent and child alike) and in the limit, and
+// limits only shrink during a walk.  So "the own box passes at the moment of the object test" already implies every
+// ancestor passed earlier: the interior boxes never change a result, they only save work -- and only if they fail
+// often enough.  Dropping interior node X (its children take its place in the depth-first array) removes one test per
+// visit of X and adds one failing test per direct child whenever X would have failed; with v = visits and p = passes
+// that is a saving iff p / v > 1 - 1 / k.  A median-split tree has many such nodes (the random scene: 40.1 -> 29.4 box
+// tests per ray, Cornell 14.6 -> 8.6, Book-2 final 55.1 -> 35.6).  The choice is an exact tree DP over (node, nearest
+// kept ancestor) on pass counts -- measured by kernel 0 on a small frame of the scene's own camera (bvh_collapse = 2),
+// or taken proportional to box surface area (1).  Order of the leaves, every leaf node and every box value are the
+// reference's; frames are bit-identical with the option on or off (tests/test_gpu_parity.py).
+// ---------------------------------------------------------------------------------------------------------------
+struct collapse_plan {
+    std::vector<char> keep;     // per reference node
+    double tests_before = 0, tests_after = 0;   // expected box tests per calibration ray
+};
+
+// children of interior node i in the depth-first array: i + 1, then each next sibling at the previous one's skip link
+template <class F> void for_children(const rt_node* nodes, int i, F f) {
+    for (int c = i + 1; c < nodes[i].skip; c = nodes[c].skip) f(c);
+}
+
+bool plan_collapse(const rt_node* nodes, int n, const std::vector<double>& pass, double root_visits, collapse_plan& plan) {
+    plan.keep.assign((size_t)n, 1);
+    if (n < 3 || root_visits <= 0) return false;
+    // depth of every node (= length of its ancestor chain); parents precede children in the array
+    std::vector<int> depth((size_t)n, 0), parent((size_t)n, -1);
+    int max_depth = 0;
+    for (int i = 0; i < n; ++i)
+        if (nodes[i].prim < 0) for_children(nodes, i, [&](int c) { depth[c] = depth[i] + 1; parent[c] = i; if (depth[c] > max_depth) max_depth = depth[c]; });
+    if (max_depth > 60) return false;   // a degenerate (list-like) tree: leave it alone
+    // the argument above needs a real tree (children tile their parent's range of the array) whose boxes contain their
+    // children's; a description that is anything else is walked as given
+    for (int i = 0; i < n; ++i) {
+        if (i > 0 && parent[i] < 0) return false;
+        if (nodes[i].prim >= 0) { if (nodes[i].skip != i + 1) return false; continue; }
+        int c = i + 1, kids = 0;
+        for (; c < nodes[i].skip; c = nodes[c].skip) {
+            ++kids;
+            for (int a = 0; a < 3; ++a)
+                if (!(nodes[c].bmin[a] >= nodes[i].bmin[a] && nodes[c].bmax[a] <= nodes[i].bmax[a])) return false;
+        }
+        if (c != nodes[i].skip || kids == 0) return false;
+    }
+    // cost[i][d]: fewest tests in the subtree of i per calibration run when the nearest kept ancestor is the d-th entry of
+    // i's ancestor chain (0 = "above the root": root_visits, 1.. = ancestors from the root down); visits of a node = passes
+    // of its nearest kept ancestor (a fixed-order walk has no other way to skip it)
+    std::vector<std::vector<double>> cost((size_t)n);
+    std::vector<int> chain;   // scratch
+    auto visits = [&](int i, int d) -> double {   // d-th entry of i's chain
+        if (d == 0) return root_visits;
+        int a = i;
+        for (int up = depth[i] - d + 1; up > 0; --up) a = parent[a];
+        return pass[a];
+    };
+    for (int i = n - 1; i >= 0; --i) {   // children have larger indices: reverse order is post-order enough
+        const int D = depth[i] + 1;
+        cost[i].assign((size_t)D, 0.0);
+        if (nodes[i].prim >= 0) { for (int d = 0; d < D; ++d) cost[i][d] = visits(i, d); continue; }
+        for (int d = 0; d < D; ++d) {
+            double keep = visits(i, d), drop = 0.0;
+            for_children(nodes, i, [&](int c) { keep += cost[c][(size_t)D]; drop += cost[c][(size_t)d]; });
+            cost[i][d] = keep <= drop ? keep : drop;
+        }
+    }
+    // decide top-down
+    std::vector<int> nearest((size_t)n, 0);
+    double before = 0.0;
+    for (int i = 0; i < n; ++i) before += (i == 0) ? root_visits : pass[parent[i]];
+    for (int i = 0; i < n; ++i) {
+        const int d = nearest[i];
+        bool keep = true;
+        if (nodes[i].prim < 0) {
+            double k = visits(i, d), drop = 0.0;
+            const int D = depth[i] + 1;
+            for_children(nodes, i, [&](int c) { k += cost[c][(size_t)D]; drop += cost[c][(size_t)d]; });
+            keep = k <= drop;
+            for_children(nodes, i, [&](int c) { nearest[c] = keep ? D : d; });
+        }
+        plan.keep[i] = keep ? 1 : 0;
+    }
+    plan.tests_before = before / root_visits;
+    plan.tests_after = cost[0][0] / root_visits;
+    return true;
+}
+
+// the walk array: kept nodes in the reference's depth-first order, skip links re-pointed at the next kept node
+std::vector<rt_node> build_walk_array(const rt_node* nodes, int n, const std::vector<char>& keep) {
+    std::vector<int> kept_before((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) kept_before[i + 1] = kept_before[i] + (keep[i] ? 1 : 0);
+    std::vector<rt_node> walk;
+    walk.reserve((size_t)kept_before[n]);
+    for (int i = 0; i < n; ++i) {
+        if (!keep[i]) continue;
+        rt_node w = nodes[i];
+        w.skip = kept_before[nodes[i].skip];
+        walk.push_back(w);
+    }
+    return walk;
+}
+
+}  // namespace
+
 extern "C" {
 
 namespace {
@@ -292,6 +407,7 @@ rt_status rt_set_option(const char* key, int value) {
     if (!key) return invalid("null option key");
     const std::string k(key);
     if (k == "kernel") { if (value != RT_KERNEL_PIXEL && value != RT_KERNEL_STAGED && value != RT_KERNEL_WAVEFRONT) return invalid("kernel: 0 (pixel), 3 (staged) or 4 (wavefront)"); g_opt.kernel = value; }
+    else if (k == "leaf_threshold") { if (value < 1 || value > 64) return invalid("leaf_threshold: 1..64"); g_opt.leaf_threshold = value; }
     else if (k == "box_threshold") { if (value < 1 || value > 64) return invalid("box_threshold: 1..64"); g_opt.box_threshold = value; }
     else if (k == "medium_threshold") { if (value < 1 || value > 64) return invalid("medium_threshold: 1..64"); g_opt.medium_threshold = value; }
     else if (k == "diel_threshold") { if (value < 1 || value > 64) return invalid("diel_threshold: 1..64"); g_opt.diel_threshold = value; }
@@ -309,6 +425,7 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "sparse_priority") { if (value < 0 || value > 3) return invalid("sparse_priority: 0..3"); g_opt.sparse_priority = value; }
     else if (k == "sparse_wg_percent") { if (value < 1 || value > 100) return invalid("sparse_wg_percent: 1..100"); g_opt.sparse_wg_percent = value; }
     else if (k == "heavy_max_tiles") { if (value < 0 || value > 4096) return invalid("heavy_max_tiles: 0..4096"); g_opt.heavy_max_tiles = value; }
+    else if (k == "bvh_collapse") { if (value < 0 || value > 2) return invalid("bvh_collapse: 0, 1 or 2 (read by rt_scene_create)"); g_opt.bvh_collapse = value; }
     else if (k == "lpt") { if (value < 0 || value > 1) return invalid("lpt: 0 or 1"); g_opt.lpt = value; }
     else if (k == "wf_slots") { if (value < 0 || value > 4096 || (value % 64)) return invalid("wf_slots: 0 or a multiple of 64 up to 4096"); g_opt.wf_slots = value; }
     else if (k == "wf_threads") { if (value != 256 && value != 512 && value != 768 && value != 1024) return invalid("wf_threads: 256, 512, 768 or 1024"); g_opt.wf_threads = value; }
@@ -341,6 +458,84 @@ rt_status rt_scene_destroy(rt_scene* s) {
     return RT_OK;
 }
 
+namespace {
+// Pass counts of the reference's nodes on a small frame through the scene's own camera (kernel 0 with its counters on).
+rt_status measure_pass_counts(rt_scene* s, std::vector<double>& pass, double& rays) {
+    const rt_camera& c = s->dev.camera;
+    const double hw = sqrt((double)c.horizontal[0] * c.horizontal[0] + (double)c.horizontal[1] * c.horizontal[1] + (double)c.horizontal[2] * c.horizontal[2]);
+    const double vh = sqrt((double)c.vertical[0] * c.vertical[0] + (double)c.vertical[1] * c.vertical[1] + (double)c.vertical[2] * c.vertical[2]);
+    double aspect = (hw > 0 && vh > 0) ? hw / vh : 1.0;
+    if (!(aspect > 0.05 && aspect < 20.0)) aspect = 1.0;
+    int nx = aspect >= 1.0 ? 256 : (int)(256 * aspect + 0.5), ny = aspect >= 1.0 ? (int)(256 / aspect + 0.5) : 256;
+    if (nx < 8) nx = 8;
+    if (ny < 8) ny = 8;
+    const int n = s->dev.n_nodes_ref;
+    unsigned int* d_pass = nullptr;
+    float* d_fb = nullptr;
+    HIPCHK(hipMalloc((void**)&d_pass, (size_t)n * sizeof(unsigned int)));
+    hipError_t e = hipMalloc((void**)&d_fb, (size_t)nx * ny * 3 * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(d_pass); HIPCHK(e); }
+    rt_frame_params fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.fb = d_fb; fp.ray_counter = s->d_ray_counter; fp.work_counter = s->d_work_counter; fp.node_pass = d_pass;
+    fp.seed_base = 1984; fp.nx = nx; fp.ny = ny; fp.ns = 4; fp.gamma = 1.0f;
+    fp.tile_rows = ny; fp.tile_first = 0; fp.tile_stride = 1; fp.local_rows = ny;
+    fp.tiles_x = (nx + 7) / 8;
+    fp.work_items = (uint32_t)fp.tiles_x * (uint32_t)((ny + 7) / 8) * 64u;
+    fp.sample_begin = 0; fp.sample_end = fp.ns;
+    rt_status st = RT_OK;
+    std::vector<unsigned int> h((size_t)n);
+    unsigned long long r = 0;
+    do {
+        if ((e = hipMemset(d_pass, 0, (size_t)n * sizeof(unsigned int))) != hipSuccess) break;
+        if ((e = hipMemset(s->d_ray_counter, 0, 256)) != hipSuccess) break;
+        if ((e = rt_launch_pixel(s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, dim3((fp.work_items + 255u) / 256u), dim3(256), nullptr)) != hipSuccess) break;
+        if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+        if ((e = hipMemcpy(h.data(), d_pass, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if ((e = hipMemcpy(&r, s->d_ray_counter, sizeof(r), hipMemcpyDeviceToHost)) != hipSuccess) break;
+    } while (0);
+    (void)hipFree(d_pass); (void)hipFree(d_fb);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; g_detail = std::string("calibration pass: ") + hipGetErrorString(e); st = RT_ERR_HIP; }
+    pass.assign((size_t)n, 0.0);
+    for (int i = 0; i < n; ++i) pass[i] = (double)h[i];
+    rays = (double)r;
+    return st;
+}
+
+// builds the walk array (see "Collapse" above) and points dev.nodes at it
+rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
+    const int n = d->n_nodes;
+    s->walk_tests_before = s->walk_tests_after = 0.0;
+    if (g_opt.bvh_collapse == 0 || n < 3) return RT_OK;
+    std::vector<double> pass;
+    double root_visits = 0.0;
+    if (g_opt.bvh_collapse == 2) {
+        const rt_status st = measure_pass_counts(s, pass, root_visits);
+        if (st != RT_OK) return st;
+    }
+    if (root_visits <= 0.0) {   // by surface area: a ray that passes a box passes a box inside it about in proportion to the areas
+        pass.assign((size_t)n, 0.0);
+        for (int i = 0; i < n; ++i) {
+            const double ex = fmax(0.0, (double)d->nodes[i].bmax[0] - d->nodes[i].bmin[0]), ey = fmax(0.0, (double)d->nodes[i].bmax[1] - d->nodes[i].bmin[1]),
+                         ez = fmax(0.0, (double)d->nodes[i].bmax[2] - d->nodes[i].bmin[2]);
+            pass[i] = 2.0 * (ex * ey + ey * ez + ex * ez);
+        }
+        root_visits = pass[0];
+    }
+    collapse_plan plan;
+    if (!plan_collapse(d->nodes, n, pass, root_visits, plan)) return RT_OK;
+    const std::vector<rt_node> walk = build_walk_array(d->nodes, n, plan.keep);
+    if ((int)walk.size() == n) return RT_OK;
+    const rt_node* d_walk = nullptr;
+    const rt_status st = upload(walk.data(), walk.size(), &d_walk);
+    if (st != RT_OK) return st;
+    s->allocs.push_back(const_cast<void*>(static_cast<const void*>(d_walk)));
+    s->dev.nodes = d_walk; s->dev.n_nodes = (int32_t)walk.size();
+    s->walk_tests_before = plan.tests_before; s->walk_tests_after = plan.tests_after;
+    return RT_OK;
+}
+}  // namespace
+
 rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!out) return invalid("null output pointer");
     *out = nullptr;
@@ -351,6 +546,15 @@ rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     rt_status st = validate(d, so, tx, uv);
     if (st != RT_OK) return st;
 
+#define UPSRC_nodes_ref nodes
+#define UPSRC_spheres spheres
+#define UPSRC_quads quads
+#define UPSRC_boxes boxes
+#define UPSRC_instances instances
+#define UPSRC_media media
+#define UPSRC_materials materials
+#define UPSRC_textures textures
+#define UPSRC_images images
     rt_scene* s = new rt_scene;
     s->device = g_device;
     memset(&s->dev, 0, sizeof(s->dev));
@@ -358,11 +562,11 @@ rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->spheres_only = so; s->tex_level = tx; s->need_uv = uv;
 #define UP(field, count)                                                             \
     do {                                                                             \
-        st = upload(d->field, (size_t)(count), &s->dev.field);                       \
+        st = upload(d->UPSRC_##field, (size_t)(count), &s->dev.field);               \
         if (st != RT_OK) { rt_scene_destroy(s); return st; }                         \
         s->allocs.push_back(const_cast<void*>(static_cast<const void*>(s->dev.field))); \
     } while (0)
-    UP(nodes, d->n_nodes);
+    UP(nodes_ref, d->n_nodes);
     UP(spheres, d->n_spheres);
     UP(quads, d->n_quads);
     UP(boxes, d->n_boxes);
@@ -372,7 +576,8 @@ rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     UP(textures, d->n_textures);
     UP(images, d->image_bytes);
 #undef UP
-    s->dev.n_nodes = d->n_nodes;
+    s->dev.n_nodes_ref = d->n_nodes;
+    s->dev.nodes = s->dev.nodes_ref; s->dev.n_nodes = d->n_nodes;     // until the walk array is built below
     s->dev.n_spheres = d->n_spheres;
     s->dev.n_materials = d->n_materials; s->dev.n_textures = d->n_textures;
     s->shade_bytes = (size_t)d->n_materials * sizeof(rt_material) + (size_t)d->n_textures * sizeof(rt_texture);
@@ -386,7 +591,19 @@ rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         rt_scene_destroy(s);
         return RT_ERR_HIP;
     }
+    st = build_walk(s, d);
+    if (st != RT_OK) { rt_scene_destroy(s); return st; }
+    s->node_bytes = (size_t)s->dev.n_nodes * sizeof(rt_node);
     *out = s;
+    return RT_OK;
+}
+
+rt_status rt_scene_walk_info(const rt_scene* s, int32_t* nodes_reference, int32_t* nodes_walked, double* tests_before, double* tests_after) {
+    if (!s) return invalid("null scene");
+    if (nodes_reference) *nodes_reference = s->dev.n_nodes_ref;
+    if (nodes_walked) *nodes_walked = s->dev.n_nodes;
+    if (tests_before) *tests_before = s->walk_tests_before;
+    if (tests_after) *tests_after = s->walk_tests_after;
     return RT_OK;
 }
 
@@ -480,6 +697,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     fp.heavy_items = 0; fp.sparse_wgs = 0; fp.sparse_stride = 1; fp.sparse_priority = g_opt.sparse_priority; fp.sparse_eager = g_opt.sparse_eager;
     fp.steps_per_trip = g_opt.steps_per_trip;
     fp.shade_threshold = g_opt.shade_threshold;
+    fp.leaf_threshold = g_opt.leaf_threshold;
     fp.diel_threshold = g_opt.diel_threshold;
     fp.box_threshold = g_opt.box_threshold; fp.medium_threshold = g_opt.medium_threshold;
     fp.newpath_threshold = g_opt.newpath_threshold;

@@ -23,7 +23,8 @@ struct rt_pixel_state {
 
 // device-resident scene: the rt_scene_desc arrays after upload
 struct rt_scene_dev {
-    const rt_node* nodes;
+    const rt_node* nodes;        // the walk array: the reference's tree in depth-first order, interior nodes that do not pay removed (rt_abi.hip, "collapse")
+    const rt_node* nodes_ref;    // the reference's tree, every node (kernel 0 and the calibration pass walk this one)
     const rt_sphere* spheres;
     const rt_quad* quads;
     const rt_box* boxes;
@@ -32,7 +33,7 @@ struct rt_scene_dev {
     const rt_material* materials;
     const rt_texture* textures;
     const uint8_t* images;
-    int32_t n_nodes, n_spheres, n_materials, n_textures;
+    int32_t n_nodes, n_nodes_ref, n_spheres, n_materials, n_textures;
     rt_camera camera;
 };
 
@@ -40,6 +41,7 @@ struct rt_frame_params {
     float* fb;                            // compact local rows, nx*3 floats each
     unsigned long long* ray_counter;      // += rays traced
     unsigned int* work_counter;           // persistent kernel's pixel queue head
+    unsigned int* node_pass;              // calibration pass (kernel 0 only): += 1 per box test of nodes_ref[i] that passed; null otherwise
     const unsigned int* tile_order;       // optional: 8x8 tiles in descending cost (LPT order); null = natural order
     unsigned int* tile_cost;              // first part of a split frame: rays per 8x8 tile
     rt_pixel_state* state_out;            // first part of a split frame: where pixels are parked (the frame is not written)
@@ -68,6 +70,7 @@ struct rt_frame_params {
     int32_t sparse_stride;                // staged kernel: in sparse mode only every sparse_stride-th lane takes a pixel
     int32_t steps_per_trip;               // persistent kernel: node visits between ballots
     int32_t shade_threshold;              // persistent kernel: waiting lanes that trigger shading
+    int32_t leaf_threshold;               // staged kernel: lanes with an object test due that trigger the leaf pass
     int32_t box_threshold, medium_threshold;   // staged kernel, general scenes: parked box/instance and medium lanes that trigger their leaf tests
     int32_t diel_threshold;               // staged kernel: dielectric hits that trigger their stage
     int32_t newpath_threshold;            // staged kernel: ended paths that trigger the new-path stage

@@ -104,10 +104,10 @@ struct SceneView {
 // ------------------------------------------------------------------ primitives
 // sphere::hit (sphere.cuh:51-89).  Returns the accepted root or a negative
 // value; exclusive bounds t > tmin && t < tmax.
-DEV bool sphere_test(const rt_sphere& s, const Ray& r, float tmin, float tmax, float& t_out) {
+// `a` = dot(r.d, r.d): the same value for every sphere a ray meets, so callers that test many compute it once
+DEV bool sphere_test_a(const rt_sphere& s, const Ray& r, float a, float tmin, float tmax, float& t_out) {
     const f3 cc = fma3(r.tm, ld3(s.vel), ld3(s.c0));
     const f3 oc = r.o - cc;
-    const float a = dot(r.d, r.d);
     const float b = dot(oc, r.d);
     const float c = fmaf(-s.radius, s.radius, dot(oc, oc));
     const float disc = fmaf(b, b, -(a * c));
@@ -118,6 +118,9 @@ DEV bool sphere_test(const rt_sphere& s, const Ray& r, float tmin, float tmax, f
     t = (-b + sq) / a;
     if (t > tmin && t < tmax) { t_out = t; return true; }
     return false;
+}
+DEV bool sphere_test(const rt_sphere& s, const Ray& r, float tmin, float tmax, float& t_out) {
+    return sphere_test_a(s, r, dot(r.d, r.d), tmin, tmax, t_out);
 }
 
 // quad::hit (quad.cuh:60-90); inclusive bounds
@@ -593,7 +596,7 @@ DEV SceneView stage_scene(const rt_scene_dev& sd, unsigned char* lds) {
 // closest hit over the whole world for one ray: bvh_node::hit from the root
 // (bvh.cuh:95-106) as a stackless walk over the depth-first node array.
 template <bool SPHERES_ONLY>
-DEV bool trace(const SceneView& sc, const Ray& r, HitInfo& best) {
+DEV bool trace(const SceneView& sc, const Ray& r, HitInfo& best, unsigned int* pass_count = nullptr) {
     const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     const float tmin = 0.001f;   // main.cu:57
     best.t = FLT_MAX; best.prim = -1; best.inst = -1;
@@ -604,6 +607,7 @@ DEV bool trace(const SceneView& sc, const Ray& r, HitInfo& best) {
         const float4 a = nodes4[2 * i], b = nodes4[2 * i + 1];
         int next = __float_as_int(a.w);   // skip link
         if (slab_test(a, b, r.o, inv, tmin, best.t)) {
+            if (pass_count) atomicAdd(&pass_count[i], 1u);   // calibration pass only (rt_abi.hip, "collapse")
             const int32_t prim = __float_as_int(b.w);
             if (prim >= 0) leaf_test<SPHERES_ONLY>(sc, prim, r, tmin, best);
             else next = i + 1;

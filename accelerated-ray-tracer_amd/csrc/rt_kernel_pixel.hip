@@ -9,7 +9,8 @@
 template <bool SPHERES_ONLY, int TEX, bool NEED_UV, int LDS_MODE>
 __global__ void __launch_bounds__(256) rt_render_pixel_kernel(rt_scene_dev sd, rt_frame_params fp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const SceneView sc = stage_scene<LDS_MODE>(sd, lds);
+    SceneView sc = stage_scene<LDS_MODE>(sd, lds);
+    sc.nodes = sd.nodes_ref; sc.n_nodes = sd.n_nodes_ref;   // every node of the reference's tree, straight from memory
 
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     int i, lrow;
@@ -27,7 +28,7 @@ __global__ void __launch_bounds__(256) rt_render_pixel_kernel(rt_scene_dev sd, r
             for (int bounce = 0; bounce < 50; ++bounce) {
                 HitInfo h;
                 ++rays;
-                if (!trace<SPHERES_ONLY>(sc, cur, h)) {
+                if (!trace<SPHERES_ONLY>(sc, cur, h, fp.node_pass)) {
                     radiance = fma3(throughput, miss_color(fp, cur), radiance);
                     break;
                 }

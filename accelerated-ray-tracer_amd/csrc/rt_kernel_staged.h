@@ -52,7 +52,9 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
     f3 inv = mk3(1, 1, 1);
     HitInfo best; best.t = FLT_MAX; best.prim = -1; best.inst = -1;
     int node = ST_NEWPATH;       // every lane starts by asking for a pixel
-    int32_t parked = -1;
+    int32_t parked = -1;         // leaf node the lane stopped at (node < 0)
+    int32_t pend = -1;           // leaf node whose box passed during the walk and whose object test is still due
+    float cur_a = 1.f;           // dot(d, d) of the current ray (sphere.cuh:58), hoisted out of the sphere tests
     bool have_pixel = false, first = true, finite_inv = true;
     unsigned int rays = 0, rays_at_pixel_start = 0;
     // Sparse mode (see rt_abi.hip, "heavy tiles"): the first fp.sparse_wgs workgroups start by serving the queue of the
@@ -162,10 +164,20 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
     for (;;) {
         DIAG_ADD(0, 1);
         // ---------------- stage A: node steps
+        // A lane whose box test passes at a leaf does not stop there: it notes the leaf (`pend`) and walks on with the
+        // limit it has; only a second leaf while the first is still due stops it (node = ~resume, `parked` = that leaf).
+        // Stage B tests the noted leaves in visiting order, each against its own box AGAIN with the limit of that
+        // moment.  This is the reference's walk exactly: bvh_node::hit (bvh.cuh:95-106) reaches an object iff every
+        // ancestor box and the object's own box (its single-object node, bvh.cuh:38-43) pass with the closest hit so
+        // far, and for a finite 1/d the slab test is monotone in the box and in the limit, so "the own box passes with
+        // the limit at the time of the object test" already implies every ancestor passed earlier with its larger
+        // limit.  Walking with a stale (larger) limit therefore visits a superset of the leaves, and the re-test in
+        // stage B keeps exactly the reference's.  Rays with a zero direction component (no monotonicity: 0 * inf) stop
+        // at every leaf, as before.
         if (__ballot(!finite_inv && (unsigned)node < (unsigned)n_nodes) == 0ull) {
             const int trip_steps = sparse ? 2 * fp.steps_per_trip : fp.steps_per_trip;
             for (int step = 0; step < trip_steps; ++step) {
-                // nobody left walking (all parked or finished): end the trip now -- this is what keeps the latency of
+                // nobody left walking (all stopped or finished): end the trip now -- this is what keeps the latency of
                 // a wave's last few live lanes near one node step per step (end of frame, small multi-GPU partitions)
                 if (__ballot((unsigned)node < (unsigned)n_nodes) == 0ull) break;
                 DIAG_ADD(1, 1); DIAG_ADD(2, __popcll(__ballot((unsigned)node < (unsigned)n_nodes)));
@@ -175,9 +187,11 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                     const int32_t prim = __float_as_int(b.w);
                     const int skip = __float_as_int(a.w);
                     const bool at_leaf = pass && prim >= 0;
+                    const bool stop = at_leaf && pend >= 0;
                     const int next = (pass && prim < 0) ? node + 1 : skip;
-                    parked = at_leaf ? prim : parked;
-                    node = at_leaf ? ~next : next;
+                    pend = (at_leaf && pend < 0) ? node : pend;
+                    parked = stop ? node : parked;
+                    node = stop ? ~next : next;
                 }
             }
         } else {   // a lane's ray has a zero direction component: the reference's own slab form for this trip
@@ -189,63 +203,89 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                     const int32_t prim = __float_as_int(b.w);
                     const int skip = __float_as_int(a.w);
                     const bool at_leaf = pass && prim >= 0;
+                    const bool stop = at_leaf && (pend >= 0 || !finite_inv);
                     const int next = (pass && prim < 0) ? node + 1 : skip;
-                    parked = at_leaf ? prim : parked;
-                    node = at_leaf ? ~next : next;
+                    pend = (at_leaf && !stop) ? node : pend;
+                    parked = stop ? node : parked;
+                    node = stop ? ~next : next;
                 }
             }
         }
-        // ---------------- stage B: leaf pass for parked lanes
-        DIAG_ADD(3, __ballot(node < 0) != 0ull); DIAG_ADD(4, __popcll(__ballot(node < 0)));
-        if (SPHERES_ONLY) {
-            if (node < 0) {
-                leaf_test<true>(sc, parked, cur, tmin, best);
-                parked = -1;
-                node = ~node;
-            }
-        } else {
-            // General scenes: spheres and quads are served every trip; boxes / instances (six quad tests, a transform)
-            // and media (two boundary tests, a private XORWOW, a logarithm) are long, so their lanes stay parked until a
-            // ballot finds enough of them -- or nobody is left who could step.
-            const int kind = node < 0 ? RT_PRIM_KIND(parked) : -1;
-            if (kind == RT_PRIM_SPHERE || kind == RT_PRIM_QUAD) {
-                float t;
-                const bool hit = kind == RT_PRIM_SPHERE ? sphere_test(sc.spheres[RT_PRIM_INDEX(parked)], cur, tmin, best.t, t)
-                                                        : quad_test(sc.quads[RT_PRIM_INDEX(parked)], cur, tmin, best.t, t);
-                if (hit) { best.t = t; best.prim = parked; best.inst = -1; }
-                parked = -1;
-                node = ~node;
-            }
+        // ---------------- stage B: leaf pass -- one object test per lane that has one due (the earliest noted leaf).
+        // A lane stopped at a second leaf resumes with that one noted; if its walk ends right there and nobody else can
+        // step either, the pass runs again at once (a wave must never reach the stage logic below with a test due and
+        // nothing walking: "nothing walking, no stage ran" is the loop's exit condition).
+        for (;;) {
+            const int cand = pend >= 0 ? pend : (node < 0 ? parked : -1);
+            const unsigned long long due_mask = __ballot(cand >= 0);
             const bool nobody_steps = __ballot((unsigned)node < (unsigned)n_nodes) == 0ull;
             const int live_b = __popcll(__ballot(node != ST_DEAD));
-            const unsigned long long box_mask = __ballot(kind == RT_PRIM_BOX || kind == RT_PRIM_INSTANCE);
-            if (box_mask != 0ull && (nobody_steps || __popcll(box_mask) >= 1 + ((fp.box_threshold - 1) * live_b >> 6))) {
-                if (kind == RT_PRIM_BOX || kind == RT_PRIM_INSTANCE) {
-                    float t;
-                    int32_t leaf = parked, inst = -1;
-                    if (solid_test(sc, parked, cur, tmin, best.t, t, leaf, inst)) { best.t = t; best.prim = leaf; best.inst = inst; }
-                    parked = -1;
-                    node = ~node;
+            DIAG_ADD(3, due_mask != 0ull); DIAG_ADD(4, __popcll(due_mask));
+            if (due_mask != 0ull && (nobody_steps || sparse || __popcll(due_mask) >= 1 + ((fp.leaf_threshold - 1) * live_b >> 6))) {
+                int kind = -1;
+                int32_t prim = -1;
+                bool box_ok = false;
+                if (cand >= 0) {
+                    const float4 a = nodes4[2 * cand], b = nodes4[2 * cand + 1];
+                    prim = __float_as_int(b.w);
+                    kind = SPHERES_ONLY ? RT_PRIM_SPHERE : RT_PRIM_KIND(prim);
+                    // the leaf's own box against the limit of THIS moment (see stage A); a ray with a zero direction
+                    // component stopped right at the leaf, so its walk-time result still stands
+                    box_ok = finite_inv ? slab_test_finite(a, b, cur.o, inv, tmin, best.t) : true;
                 }
-            }
-            const unsigned long long med_mask = __ballot(kind == RT_PRIM_MEDIUM);
-            if (med_mask != 0ull && (nobody_steps || __popcll(med_mask) >= 1 + ((fp.medium_threshold - 1) * live_b >> 6))) {
-                if (kind == RT_PRIM_MEDIUM) {
-                    float t;
-                    if (medium_test(sc, sc.media[RT_PRIM_INDEX(parked)], cur, tmin, best.t, t)) { best.t = t; best.prim = parked; best.inst = -1; }
-                    parked = -1;
-                    node = ~node;
+                // the tested leaf is done: a lane stopped at a second leaf walks on with that one noted
+                bool tested = false;
+                if (SPHERES_ONLY) {
+                    if (cand >= 0) {
+                        float t;
+                        if (box_ok && sphere_test_a(sc.spheres[RT_PRIM_INDEX(prim)], cur, cur_a, tmin, best.t, t)) { best.t = t; best.prim = prim; best.inst = -1; }
+                        tested = true;
+                    }
+                } else {
+                    // General scenes: spheres and quads are served by every pass; boxes / instances (six quad tests, a
+                    // transform) and media (two boundary tests, a private XORWOW, a logarithm) are long, so their lanes
+                    // wait until a ballot finds enough of them -- or nobody is left who could step.
+                    if (kind == RT_PRIM_SPHERE || kind == RT_PRIM_QUAD) {
+                        float t;
+                        const bool hit = box_ok && (kind == RT_PRIM_SPHERE ? sphere_test_a(sc.spheres[RT_PRIM_INDEX(prim)], cur, cur_a, tmin, best.t, t)
+                                                                           : quad_test(sc.quads[RT_PRIM_INDEX(prim)], cur, tmin, best.t, t));
+                        if (hit) { best.t = t; best.prim = prim; best.inst = -1; }
+                        tested = true;
+                    }
+                    const unsigned long long box_mask = __ballot(kind == RT_PRIM_BOX || kind == RT_PRIM_INSTANCE);
+                    if (box_mask != 0ull && (nobody_steps || __popcll(box_mask) >= 1 + ((fp.box_threshold - 1) * live_b >> 6))) {
+                        if (kind == RT_PRIM_BOX || kind == RT_PRIM_INSTANCE) {
+                            float t;
+                            int32_t leaf = prim, inst = -1;
+                            if (box_ok && solid_test(sc, prim, cur, tmin, best.t, t, leaf, inst)) { best.t = t; best.prim = leaf; best.inst = inst; }
+                            tested = true;
+                        }
+                    }
+                    const unsigned long long med_mask = __ballot(kind == RT_PRIM_MEDIUM);
+                    if (med_mask != 0ull && (nobody_steps || __popcll(med_mask) >= 1 + ((fp.medium_threshold - 1) * live_b >> 6))) {
+                        if (kind == RT_PRIM_MEDIUM) {
+                            float t;
+                            if (box_ok && medium_test(sc, sc.media[RT_PRIM_INDEX(prim)], cur, tmin, best.t, t)) { best.t = t; best.prim = prim; best.inst = -1; }
+                            tested = true;
+                        }
+                    }
                 }
+                if (tested) {
+                    if (node < 0) { pend = pend >= 0 ? parked : -1; parked = -1; node = ~node; }
+                    else pend = -1;
+                }
+                if (nobody_steps && __ballot((unsigned)node < (unsigned)n_nodes) == 0ull && __ballot(pend >= 0 || node < 0) != 0ull) continue;
             }
+            break;
         }
         // a finished walk that hit nothing (main.cu:57-68) needs no stage: add the background and end the path now
-        if (node == ST_DONE && best.prim < 0) {
+        if (node == ST_DONE && pend < 0 && best.prim < 0) {
             radiance = fma3(throughput, miss_color(fp, cur), radiance);
             node = ST_NEWPATH;
         }
         const unsigned long long walking = __ballot(node < n_nodes);
         const bool force = walking == 0ull;
-        const int n_done = __popcll(__ballot(node == ST_DONE));
+        const int n_done = __popcll(__ballot(node == ST_DONE && pend < 0));
         bool ran_stage = false;
         // The thresholds are fractions of the lanes that still have work: a wave whose lanes are running out of pixels
         // (end of the frame, or a small row partition on a multi-GPU run) must not wait for 24 lanes it no longer has.
@@ -259,8 +299,8 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
         if (n_done > 0 && (n_done >= shade_need || force || eager)) {
             ran_stage = true;
             DIAG_ADD(5, 1); DIAG_ADD(6, n_done);
-            DIAG_ADD(11, __popcll(__ballot(node == ST_DONE && best.prim >= 0)));
-            if (node == ST_DONE) {
+            DIAG_ADD(11, __popcll(__ballot(node == ST_DONE && pend < 0 && best.prim >= 0)));
+            if (node == ST_DONE && pend < 0) {
                 {
                     const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, best);
                     const rt_material m = sc.materials[rec.mat];
@@ -401,6 +441,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
             if (node == ST_SETUP) {
                 inv = mk3(1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z);
                 finite_inv = inv_is_finite(inv);
+                cur_a = dot(cur.d, cur.d);
                 best.t = FLT_MAX; best.prim = -1; best.inst = -1;
                 node = n_nodes > 0 ? 0 : ST_DONE;
                 ++rays;

@@ -195,6 +195,13 @@ const char* rt_last_error_detail(void); /* "file:line 'expr'" of the last failur
 rt_status rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
 rt_status rt_scene_destroy(rt_scene* scene);
 
+/* The traversal array behind a scene.  rt_scene_create keeps the reference's depth-first tree and, beside it, the array
+ * the render kernels walk: the same leaves in the same order, with the interior nodes whose box test does not pay
+ * removed (option "bvh_collapse", read at creation; results are bit-identical either way).  Reports the two
+ * node counts and the expected box tests per ray before / after on the calibration frame (0 when nothing was removed). */
+rt_status rt_scene_walk_info(const rt_scene* scene, int32_t* nodes_reference, int32_t* nodes_walked,
+                             double* tests_before, double* tests_after);
+
 /* Number of rows a frame description assigns to this call, and the mapping
  * from a compact local row to its global row. */
 int32_t rt_frame_local_rows(const rt_frame_desc* f);

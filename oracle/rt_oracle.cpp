@@ -158,6 +158,7 @@ struct Counters {
                        medium_calls = 0, box6_calls = 0, inst_calls = 0, samples = 0;
 };
 thread_local Counters* g_cnt = nullptr;
+bool g_node_stats = false;   // diagnostics only: count passing box tests per bvh node (orc_node_passes)
 
 // slab test, aabb.cuh:45-61 (three IEEE divides, ternary min/max, <= reject)
 inline bool box_hit(const Box& b, const Ray& r, float tmin, float tmax) {
@@ -386,6 +387,7 @@ struct Obj {
     float sin_t = 0, cos_t = 1;            // rotate_y
     float neg_inv_density = 0;             // medium
     const Obj* left = nullptr; const Obj* right = nullptr;
+    mutable unsigned long long stat_pass = 0;   // diagnostics (orc_node_passes): box tests of this bvh node that passed
 };
 
 bool obj_hit(const Obj* o, const Ray& r, float tmin, float tmax, Hit& rec);
@@ -509,6 +511,7 @@ bool medium_hit(const Obj* m, const Ray& r, float tmin, float tmax, Hit& rec) {
 
 bool bvh_hit(const Obj* n, const Ray& r, float tmin, float tmax, Hit& rec) {         // bvh.cuh:95-106
     if (!box_hit(n->bbox, r, tmin, tmax)) return false;
+    if (g_node_stats) __atomic_fetch_add(&n->stat_pass, 1ull, __ATOMIC_RELAXED);
     Hit lrec, rrec;
     const bool hl = n->left ? obj_hit(n->left, r, tmin, tmax, lrec) : false;
     const bool hr = n->right ? obj_hit(n->right, r, tmin, hl ? lrec.t : tmax, rrec) : false;
@@ -1172,6 +1175,20 @@ int orc_dump_nodes(int h, float* out, int cap_nodes) {
     int n = (int)(v.size() / 8);
     if (out) for (int k = 0; k < n && k < cap_nodes; ++k) memcpy(out + 8 * k, v.data() + 8 * k, 32);
     return n;
+}
+
+// Diagnostics for tools/ (never used by a parity test): per-node count of box tests that passed since the last reset, in
+// the DFS pre-order of orc_dump_nodes.  enable != 0 switches the counting on and clears the counters.
+static void node_pass_rec(const Obj* n, std::vector<unsigned long long>* out, bool clear) {
+    if (out) out->push_back(n->stat_pass);
+    if (clear) n->stat_pass = 0;
+    if (n->left != n->right) { node_pass_rec(n->left, out, clear); node_pass_rec(n->right, out, clear); }
+}
+void orc_node_stats_enable(int h, int enable) { g_node_stats = enable != 0; node_pass_rec(g_scenes[h]->world, nullptr, true); }
+int orc_node_passes(int h, unsigned long long* out, int cap) {
+    std::vector<unsigned long long> v; node_pass_rec(g_scenes[h]->world, &v, false);
+    for (int k = 0; k < (int)v.size() && k < cap; ++k) out[k] = v[k];
+    return (int)v.size();
 }
 
 // scene census: out[0..] = list size, spheres, moving spheres, quads(in list), boxes, instances(translate), media,

@@ -72,6 +72,38 @@ def test_scene_matches_oracle(gpu, orc, name, nx, ny, ns):
     assert_frames_equal(fb, ref, name)
 
 
+@pytest.mark.parametrize("name,nx,ny,ns", [("bouncing", 160, 96, 8), ("cornell", 64, 64, 8), ("cornell_smoke", 64, 64, 8), ("final", 64, 64, 4), ("degenerate", 32, 16, 8)])
+def test_walk_array_is_invisible(gpu, orc, name, nx, ny, ns):
+    """rt_scene_create drops the interior nodes of the reference's tree whose box test does not pay (option bvh_collapse:
+    0 = none, 1 = chosen by surface area, 2 = by measured pass counts).  Interior boxes never change what bvh_node::hit
+    returns (bvh.cuh:95-106; see rt_abi.hip "Collapse"), so all three must give the oracle's frame and ray count, and the
+    walk array must keep every leaf in the reference's order."""
+    img, iw, ih = gpu.default_texture(name)
+    hs = gpu.HostScene(name, nx, ny, img, iw, ih)
+    ref, cnt = orc.OracleScene(name, nx, ny, img, iw, ih).render(ns)
+    sizes = {}
+    for mode in (0, 1, 2):
+        gpu.reset_options()
+        gpu.set_option("bvh_collapse", mode)
+        ds = gpu.DeviceScene(hs)
+        try:
+            info = ds.walk_info()
+            gpu.reset_options()
+            fb, st = ds.render(hs.frame(ns=ns))
+        finally:
+            ds.close()
+        assert st.rays == cnt["rays"], (mode, st.rays, cnt["rays"])
+        assert_frames_equal(fb, ref, f"{name} bvh_collapse={mode}")
+        assert info["nodes_reference"] == hs.desc.n_nodes
+        sizes[mode] = info["nodes_walked"]
+        n_leaves = int((hs.nodes()["prim"] >= 0).sum())
+        assert n_leaves <= info["nodes_walked"] <= info["nodes_reference"]
+        if mode and info["nodes_walked"] < info["nodes_reference"]:
+            assert info["tests_after"] < info["tests_before"]
+    assert sizes[0] == hs.desc.n_nodes
+    print(name, sizes)
+
+
 def test_ragged_sizes_and_edge_frames(gpu, orc):
     """Frame sizes that are not multiples of the 8x8 work tiles, single rows/columns, 1 spp, gamma 1."""
     for nx, ny, ns, gamma in [(37, 19, 3, None), (1, 1, 5, None), (65, 1, 2, None), (3, 70, 1, None), (40, 24, 4, 1.0)]:
@@ -146,14 +178,17 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
                 (3, {"threads": 64, "wg_per_cu": 8, "shade_threshold": 40, "newpath_threshold": 3}),
                 (4, {}), (4, {"wf_threads": 1024, "lds_mode": 1}), (4, {"wf_threads": 256, "wf_slots": 384, "wf_wg_per_cu": 3, "lds_mode": 0, "wf_pause_lanes": 64}),
                 (4, {"wf_pause_lanes": 1, "steps_per_trip": 3}),
-                (0, {"lds_mode": 0})]
+                (0, {"lds_mode": 0}), (3, {"bvh_collapse": 0}), (3, {"bvh_collapse": 1}), (3, {"bvh_collapse": 1, "leaf_threshold": 1, "steps_per_trip": 3}),
+                (3, {"bvh_collapse": 0, "leaf_threshold": 64, "steps_per_trip": 20}), (3, {"leaf_threshold": 1}), (3, {"leaf_threshold": 33, "steps_per_trip": 2}),
+                (4, {"bvh_collapse": 0}), (4, {"bvh_collapse": 1})]
     for kernel, opts in variants:
         fb, st = render(gpu, hs, kernel, opts, ns=6)
         assert st.rays == st0.rays, (kernel, opts)
         assert np.array_equal(fb.view(np.uint32), base.view(np.uint32)), (kernel, opts)
     hs2 = gpu.HostScene("cornell_smoke", 48, 48)
     base2, _ = render(gpu, hs2, 0, ns=4)
-    for kernel, opts in [(3, {}), (3, {"lds_mode": 0, "diel_threshold": 1}), (3, {"lds_mode": 1, "box_threshold": 1, "medium_threshold": 1}), (3, {"steps_per_trip": 2, "shade_threshold": 60, "box_threshold": 64, "medium_threshold": 64})]:
+    for kernel, opts in [(3, {}), (3, {"lds_mode": 0, "diel_threshold": 1}), (3, {"lds_mode": 1, "box_threshold": 1, "medium_threshold": 1}), (3, {"steps_per_trip": 2, "shade_threshold": 60, "box_threshold": 64, "medium_threshold": 64}),
+                         (3, {"bvh_collapse": 0}), (3, {"bvh_collapse": 1, "leaf_threshold": 1}), (3, {"bvh_collapse": 2, "leaf_threshold": 40, "steps_per_trip": 5})]:
         fb, _ = render(gpu, hs2, kernel, opts, ns=4)
         assert np.array_equal(fb.view(np.uint32), base2.view(np.uint32)), (kernel, opts)
 
