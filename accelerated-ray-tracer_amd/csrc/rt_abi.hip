@@ -119,8 +119,8 @@ struct rt_scene {
     unsigned long long* d_heavy_list = nullptr;   // (cost << 32 | pixel), unsorted, from rt_collect_heavy_kernel
     unsigned int* d_heavy_pixels = nullptr;       // heavy pixels, dearest first
     size_t tile_capacity = 0, pixel_capacity = 0;
-    std::vector<unsigned int> h_tile_cost, h_tile_order, h_heavy_pixels;
-    std::vector<unsigned long long> h_heavy;
+    rt_rank_info* d_rank = nullptr;               // tier sizes of the next ranked launch (written and read on the device only)
+    bool ranked_frame = false;                    // the pending frame used the cost-aware schedule
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool frame_pending = false;
     hipStream_t pending_stream = nullptr;
@@ -452,6 +452,7 @@ rt_status rt_scene_destroy(rt_scene* s) {
     if (s->d_state) (void)hipFree(s->d_state);
     if (s->d_heavy_list) (void)hipFree(s->d_heavy_list);
     if (s->d_heavy_pixels) (void)hipFree(s->d_heavy_pixels);
+    if (s->d_rank) (void)hipFree(s->d_rank);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
     delete s;
@@ -638,6 +639,11 @@ rt_status rt_frame_finish(rt_scene* s, rt_stats* stats) {
     if (err_flag) { s->frame_pending = false; g_detail = "render kernel hit its iteration cap (scheduler bug); frame is incomplete"; return RT_ERR_HIP; }
     s->pending_stats.ms_render = (double)ms;
     s->pending_stats.rays = rays;
+    if (s->ranked_frame && s->d_rank) {   // how many pixels the last ranking listed as heavy (diagnostics)
+        rt_rank_info inf;
+        HIPCHK(hipMemcpy(&inf, s->d_rank, sizeof(inf), hipMemcpyDeviceToHost));
+        s->pending_stats.reserved = (int32_t)inf.heavy_items;
+    }
     s->frame_pending = false;
     if (stats) *stats = s->pending_stats;
     return RT_OK;
@@ -694,7 +700,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     const int tiles_y = (local_rows + 7) / 8;
     if ((long long)fp.tiles_x * tiles_y * 64 >= (1ll << 31)) return invalid("frame too large");
     fp.work_items = (uint32_t)fp.tiles_x * (uint32_t)tiles_y * 64u;
-    fp.heavy_items = 0; fp.sparse_wgs = 0; fp.sparse_stride = 1; fp.sparse_priority = g_opt.sparse_priority; fp.sparse_eager = g_opt.sparse_eager;
+    fp.sparse_priority = g_opt.sparse_priority; fp.sparse_eager = g_opt.sparse_eager;
     fp.steps_per_trip = g_opt.steps_per_trip;
     fp.shade_threshold = g_opt.shade_threshold;
     fp.leaf_threshold = g_opt.leaf_threshold;
@@ -788,7 +794,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     }
     // tier 0 of the cost-aware schedule (spheres-only scenes resident in LDS): per-workgroup scratch behind the scene
     // data -- header (16 B), 2 x 16 reduction slots (256 B), the leaf list (4 B per node: at most that many leaves)
-    fp.tier0_items = 0; fp.tier0_wgs = 0; fp.tier0_lds_offset = 0;
+    fp.tier0_lds_offset = 0;
     bool tier0_possible = false;
     if (kernel == RT_KERNEL_STAGED && s->spheres_only && lds_mode == 2 && (g_opt.tier0_auto || g_opt.tier0_pixels > 0) && block.x >= 64 && block.x <= 1024) {
         const size_t scratch = ((size_t)16 + 256 + (size_t)s->dev.n_nodes * 4 + 255) & ~(size_t)255;
@@ -810,39 +816,44 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     // is in flight, so that is the whole state.  With those measured costs part 2 renders samples [S0, ns):
     //   * 8x8 tiles are served in descending cost (longest first);
     //   * pixels far above the mean go to a short list, dearest first, served by "sparse" workgroups at raised
-    //     priority: tier 1 (the very dearest) one live lane per wave, tier 2 a few -- a lane's rays advance about
-    //     twice as fast in a wave with few live lanes; ordinary waves skip listed pixels.
-    // Scheduling only: every sample of every pixel is rendered exactly once, in its pixel's stream order; frames are
-    // bit-identical with and without it (tests sweep the knobs).
-    fp.tile_order = nullptr; fp.tile_cost = nullptr; fp.state_out = nullptr; fp.state_in = nullptr; fp.heavy_pixels = nullptr;
+    //     priority: tier 0 (the very dearest, spheres-only scenes) a whole workgroup per pixel, tier 1 one live lane
+    //     per wave, tier 2 a few -- a lane's rays advance about twice as fast in a wave with few live lanes; ordinary
+    //     waves skip listed pixels.
+    // The ranking runs on the device (rt_rank.hip) and leaves the tier sizes in device memory, so the whole frame is
+    // enqueued without a host round trip.  Scheduling only: every sample of every pixel is rendered exactly once, in
+    // its pixel's stream order; frames are bit-identical with and without it (tests sweep the knobs).
+    fp.tile_order = nullptr; fp.tile_cost = nullptr; fp.state_out = nullptr; fp.state_in = nullptr; fp.heavy_pixels = nullptr; fp.rank = nullptr;
     fp.sample_begin = 0; fp.sample_end = f->ns;
-    fp.heavy_threshold = 0xFFFFFFFFu; fp.tier1_items = 0; fp.tier1_wgs = 0; fp.tier1_stride = 64;
     const size_t n_tiles = (size_t)fp.tiles_x * (size_t)tiles_y;
     const size_t n_pixels = (size_t)local_rows * (size_t)f->nx;
     enum { RT_HEAVY_CAP = 32768 };
-    bool split = false;
+    s->ranked_frame = false;
     HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 256, stream));
     if (g_opt.lpt && kernel == RT_KERNEL_STAGED && f->ns >= 2 * g_opt.split_samples && n_tiles >= 64 && n_pixels < (1ull << 31)) {
-        if (s->tile_capacity < n_tiles || s->pixel_capacity < n_pixels) {
-            for (void* p : {(void*)s->d_tile_cost, (void*)s->d_tile_order, (void*)s->d_state, (void*)s->d_heavy_list, (void*)s->d_heavy_pixels})
+        if (s->tile_capacity < n_tiles || s->pixel_capacity < n_pixels || !s->d_rank) {
+            for (void* p : {(void*)s->d_tile_cost, (void*)s->d_tile_order, (void*)s->d_state, (void*)s->d_heavy_list, (void*)s->d_heavy_pixels, (void*)s->d_rank})
                 if (p) (void)hipFree(p);
-            s->d_tile_cost = s->d_tile_order = s->d_heavy_pixels = nullptr; s->d_state = nullptr; s->d_heavy_list = nullptr;
+            s->d_tile_cost = s->d_tile_order = s->d_heavy_pixels = nullptr; s->d_state = nullptr; s->d_heavy_list = nullptr; s->d_rank = nullptr;
             s->tile_capacity = s->pixel_capacity = 0;
             HIPCHK(hipMalloc((void**)&s->d_tile_cost, n_tiles * sizeof(unsigned int)));
             HIPCHK(hipMalloc((void**)&s->d_tile_order, n_tiles * sizeof(unsigned int)));
             HIPCHK(hipMalloc((void**)&s->d_state, n_pixels * sizeof(rt_pixel_state)));
             HIPCHK(hipMalloc((void**)&s->d_heavy_list, (size_t)RT_HEAVY_CAP * sizeof(unsigned long long)));
             HIPCHK(hipMalloc((void**)&s->d_heavy_pixels, (size_t)RT_HEAVY_CAP * sizeof(unsigned int)));
+            HIPCHK(hipMalloc((void**)&s->d_rank, sizeof(rt_rank_info)));
             s->tile_capacity = n_tiles; s->pixel_capacity = n_pixels;
         }
-        // One ranked part: reads what the pixels cost so far, orders the tiles, lists the heavy pixels and sizes the
-        // tiers for the launch described by `q` (which resumes every pixel from d_state).
+        // One ranked part: three small kernels order the tiles, list the heavy pixels and size the tiers for the launch
+        // described by `q` (which resumes every pixel from d_state).  The grid is fixed here, before the sizes are known:
+        // the workgroups the ordinary queue needs plus the most the tiers may take; a workgroup that finds both its
+        // queues empty leaves at once.
+        const unsigned max_grid = (unsigned)(g_num_cu * per_cu_resident);
         auto rank_pixels = [&](rt_frame_params& q, dim3& grid_q) -> rt_status {
             // Effective tier sizes.  Whether a whole workgroup per ray pays depends on how much idle hardware there is per
             // heavy pixel, i.e. on the share of the frame this call renders (1/N in an N-GPU run): measured on rank-local
             // renders of the headline frame (tools/partition_time.py, profiles/r01i_partition_times.log) the whole frame
-            // is best with no tier 0 (it is throughput-bound; 132.5 vs 135-140 ms), half a frame with a moderate one,
-            // a quarter or less with every pixel above twice the mean on tier-0 workgroups (N = 8: 124.5 -> 85 ms).
+            // is best with no tier 0 (it is throughput-bound), half a frame with a moderate one, a quarter or less with
+            // every pixel above twice the mean on tier-0 workgroups.
             int e_tier0_pixels = g_opt.tier0_pixels, e_tier0_factor = g_opt.tier0_factor_x10, e_tier1_pixels = g_opt.tier1_pixels,
                 e_heavy_factor = g_opt.heavy_factor_x10, e_sparse_percent = g_opt.sparse_wg_percent;
             if (g_opt.tier0_auto) {
@@ -851,75 +862,24 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
                 else if (share > 0.375) { e_tier0_pixels = 1024; e_tier0_factor = 40; e_tier1_pixels = 256; e_heavy_factor = 35; e_sparse_percent = 50; }
                 else { e_tier0_pixels = 4096; e_tier0_factor = 20; e_tier1_pixels = 0; e_heavy_factor = 20; e_sparse_percent = 80; }
             }
-            unsigned long long rays_so_far = 0;
-            s->h_tile_cost.resize(n_tiles); s->h_tile_order.resize(n_tiles);
-            HIPCHK(hipMemcpyAsync(s->h_tile_cost.data(), s->d_tile_cost, n_tiles * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(&rays_so_far, s->d_ray_counter, sizeof(rays_so_far), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            // ---- tiles, dearest first
-            for (size_t t = 0; t < n_tiles; ++t) s->h_tile_order[t] = (unsigned int)t;
-            const unsigned int* cost = s->h_tile_cost.data();
-            std::stable_sort(s->h_tile_order.begin(), s->h_tile_order.end(), [cost](unsigned int a, unsigned int b) { return cost[a] > cost[b]; });
-            HIPCHK(hipMemcpyAsync(s->d_tile_order, s->h_tile_order.data(), n_tiles * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
-            q.tile_order = s->d_tile_order;
-            q.heavy_pixels = nullptr; q.heavy_threshold = 0xFFFFFFFFu; q.heavy_items = 0; q.tier1_items = 0; q.tier1_wgs = 0; q.tier1_stride = 64;
-            q.sparse_wgs = 0; q.tier0_items = 0; q.tier0_wgs = 0;
-            // ---- heavy pixels
-            if (!(g_opt.sparse_stride > 0 && block.x >= 64)) return RT_OK;
-            const double mean = (double)rays_so_far / (double)n_pixels;                    // rays per pixel so far
-            const unsigned int threshold = (unsigned int)(mean * (double)e_heavy_factor / 10.0 + 0.999);
-            const unsigned int threshold1 = (unsigned int)(mean * (double)g_opt.tier1_factor_x10 / 10.0 + 0.999);
-            const unsigned int threshold0 = (unsigned int)(mean * (double)e_tier0_factor / 10.0 + 0.999);
-            unsigned int* d_count = s->d_work_counter + 8;
-            HIPCHK(hipMemsetAsync(d_count, 0, sizeof(unsigned int), stream));
-            rt_launch_collect_heavy(s->d_state, (unsigned int)n_pixels, threshold, s->d_heavy_list, RT_HEAVY_CAP, d_count, stream);
-            HIPCHK(hipGetLastError());
-            unsigned int count = 0;
-            HIPCHK(hipMemcpyAsync(&count, d_count, sizeof(count), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            if (!(count > 0 && count <= RT_HEAVY_CAP && (size_t)count * 8 < n_pixels)) return RT_OK;
-            s->h_heavy.resize(count);
-            HIPCHK(hipMemcpyAsync(s->h_heavy.data(), s->d_heavy_list, (size_t)count * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            std::sort(s->h_heavy.begin(), s->h_heavy.end(), [](unsigned long long a, unsigned long long b) { return a > b; });
-            s->h_heavy_pixels.resize(count);
-            unsigned tier1_items = 0, tier0_items = 0;
-            for (unsigned int k = 0; k < count; ++k) {
-                s->h_heavy_pixels[k] = (unsigned int)(s->h_heavy[k] & 0xFFFFFFFFull);
-                if ((unsigned int)(s->h_heavy[k] >> 32) >= threshold1) tier1_items = k + 1;
-                if ((unsigned int)(s->h_heavy[k] >> 32) >= threshold0) tier0_items = k + 1;
-            }
-            HIPCHK(hipMemcpyAsync(s->d_heavy_pixels, s->h_heavy_pixels.data(), (size_t)count * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipStreamSynchronize(stream));   // h_heavy_pixels is reused by the next ranked part
-            // workgroups: tier 1 = one live lane per wave, tier 2 = 64 / sparse_stride live lanes per wave
-            const unsigned waves_per_wg = block.x / 64u;
-            const unsigned max_grid = (unsigned)(g_num_cu * per_cu_resident);
-            const unsigned cap_wgs = max_grid * (unsigned)e_sparse_percent / 100u;
-            // tier 0: the very dearest, one per workgroup (each workgroup serves its share of the list one pixel after the other)
-            unsigned tier0_wgs = 0;
-            if (!tier0_possible) tier0_items = 0;
-            if (tier0_items > (unsigned)e_tier0_pixels) tier0_items = (unsigned)e_tier0_pixels;
-            if (tier0_items > cap_wgs / 2) tier0_items = cap_wgs / 2;
-            tier0_wgs = tier0_items;
-            tier1_items = tier1_items > tier0_items ? tier1_items - tier0_items : 0;       // tier 1 follows tier 0 in the list
-            if (tier1_items > (unsigned)e_tier1_pixels) tier1_items = (unsigned)e_tier1_pixels;
-            unsigned tier1_wgs = (tier1_items + waves_per_wg - 1) / waves_per_wg;
-            if (tier0_wgs + tier1_wgs > cap_wgs / 2 + tier0_wgs / 2) { tier1_wgs = cap_wgs / 2 > tier0_wgs / 2 ? cap_wgs / 2 - tier0_wgs / 2 : 0; tier1_items = tier1_wgs * waves_per_wg; if (tier0_items + tier1_items > count) tier1_items = count - tier0_items; }
-            const unsigned tier2_items = count - tier0_items - tier1_items;
-            const unsigned per_wg2 = waves_per_wg * (64u / (unsigned)g_opt.sparse_stride);
-            unsigned tier2_wgs = (tier2_items + per_wg2 - 1) / per_wg2;
-            if (tier0_wgs + tier1_wgs + tier2_wgs > cap_wgs) tier2_wgs = cap_wgs > tier0_wgs + tier1_wgs ? cap_wgs - tier0_wgs - tier1_wgs : 0;     // the rest of tier 2 queues behind them
-            const unsigned sparse_wgs = tier0_wgs + tier1_wgs + tier2_wgs;
-            const unsigned normal_need = (unsigned)((q.work_items + block.x - 1) / block.x);
-            unsigned total = normal_need + sparse_wgs;
+            rt_rank_params rp;
+            memset(&rp, 0, sizeof(rp));
+            rp.state = s->d_state; rp.tile_cost = s->d_tile_cost; rp.tile_order = s->d_tile_order; rp.ray_counter = s->d_ray_counter;
+            rp.heavy_list = s->d_heavy_list; rp.heavy_pixels = s->d_heavy_pixels; rp.info = s->d_rank;
+            rp.n_pixels = (uint32_t)n_pixels; rp.n_tiles = (uint32_t)n_tiles; rp.heavy_cap = RT_HEAVY_CAP;
+            rp.max_grid = max_grid; rp.waves_per_wg = block.x / 64u;
+            rp.normal_need = (uint32_t)((q.work_items + block.x - 1) / block.x);
+            rp.sparse_stride = (g_opt.sparse_stride > 0 && block.x >= 64) ? g_opt.sparse_stride : 0;
+            rp.sparse_percent = e_sparse_percent;
+            rp.tier0_possible = tier0_possible ? 1 : 0;
+            rp.tier0_pixels = e_tier0_pixels; rp.tier1_pixels = e_tier1_pixels;
+            rp.heavy_factor = (float)e_heavy_factor / 10.0f; rp.tier1_factor = (float)g_opt.tier1_factor_x10 / 10.0f; rp.tier0_factor = (float)e_tier0_factor / 10.0f;
+            HIPCHK(rt_launch_rank(rp, stream));
+            q.tile_order = s->d_tile_order; q.heavy_pixels = s->d_heavy_pixels; q.rank = s->d_rank;
+            unsigned total = rp.normal_need + (rp.sparse_stride > 0 ? max_grid * (unsigned)e_sparse_percent / 100u : 0u);
             if (total > max_grid) total = max_grid;
-            if (sparse_wgs > 0 && total > sparse_wgs) {
-                grid_q = dim3(total);
-                q.heavy_pixels = s->d_heavy_pixels; q.heavy_threshold = threshold;
-                q.heavy_items = count; q.tier1_items = tier1_items; q.tier1_wgs = (int32_t)tier1_wgs; q.tier1_stride = 64;
-                q.tier0_items = tier0_items; q.tier0_wgs = (int32_t)tier0_wgs;
-                q.sparse_wgs = (int32_t)sparse_wgs; q.sparse_stride = g_opt.sparse_stride;
-            }
+            if (total < 1u) total = 1u;
+            grid_q = dim3(total);
             return RT_OK;
         };
         // ---- part 1: samples [0, S_a) -- every pixel alike (nothing is known yet); S_a = presplit_samples, or S0
@@ -942,14 +902,13 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             HIPCHK(launch_render(kernel, lds_mode, s, p2, grid2, block, lds_bytes, stream));
         }
         // ---- part 2: samples [S0, ns), ranked on the first S0 samples
-        split = true;
         fp.state_in = s->d_state; fp.sample_begin = g_opt.split_samples;
         const rt_status st3 = rank_pixels(fp, grid);
         if (st3 != RT_OK) return st3;
         out.workgroups = (int)grid.x;
+        s->ranked_frame = true;
     }
-    (void)split;
-    out.reserved = (int32_t)fp.heavy_items;
+    out.reserved = 0;
     HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));   // the ray counter keeps part 1's rays
     HIPCHK(launch_render(kernel, lds_mode, s, fp, grid, block, lds_bytes, stream));
     HIPCHK(hipEventRecord(s->ev_stop, stream));

@@ -21,6 +21,40 @@ struct rt_pixel_state {
     uint32_t cost;
 };
 
+// What the ranking kernels (rt_rank.hip) leave for the next render launch of a split frame: how many parked pixels are
+// "heavy", how the heavy list is cut into tiers and how many workgroups serve each.  Lives in device memory; the render
+// kernel reads it at its start, the host never does (a frame is one stream enqueue, no round trip).
+struct rt_rank_info {
+    uint32_t heavy_items;        // entries of heavy_pixels (dearest first); 0 = no list
+    uint32_t heavy_threshold;    // pixels whose parked cost is >= this are in the list (ordinary waves skip them)
+    uint32_t tier0_items;        // leading entries served one per WORKGROUP (tier 0)
+    uint32_t tier1_items;        // following entries served one per WAVE (tier 1); the rest go to sparse waves (tier 2)
+    int32_t tier0_wgs, tier1_wgs;   // workgroups [0, tier0_wgs) are tier 0, the next tier1_wgs tier 1
+    int32_t sparse_wgs;          // workgroups [0, sparse_wgs) start in sparse mode (tiers 0, 1, 2)
+    int32_t sparse_stride;       // sparse waves: every sparse_stride-th lane takes a pixel
+    uint32_t threshold0, threshold1;   // costs that qualify for tier 0 / tier 1 (set with heavy_threshold by the first ranking kernel)
+    uint32_t collected;          // entries rt_collect_heavy_kernel appended (may exceed the capacity: then there is no list)
+    uint32_t pad;
+};
+
+// constants of one ranking (host-filled kernel argument)
+struct rt_rank_params {
+    const rt_pixel_state* state;
+    const unsigned int* tile_cost;
+    unsigned int* tile_order;
+    const unsigned long long* ray_counter;
+    unsigned long long* heavy_list;      // scratch: (cost << 32 | pixel), unsorted
+    unsigned int* heavy_pixels;          // out: pixel ids, dearest first
+    rt_rank_info* info;
+    uint32_t n_pixels, n_tiles, heavy_cap;
+    uint32_t max_grid, waves_per_wg, normal_need;
+    int32_t sparse_stride;               // 0 = no heavy list at all
+    int32_t sparse_percent;              // at most this share of max_grid starts in sparse mode
+    int32_t tier0_possible;              // tier 0 needs a spheres-only scene resident in LDS
+    int32_t tier0_pixels, tier1_pixels;  // caps on the tier sizes
+    float heavy_factor, tier1_factor, tier0_factor;   // cost thresholds as multiples of the mean cost per pixel
+};
+
 // device-resident scene: the rt_scene_desc arrays after upload
 struct rt_scene_dev {
     const rt_node* nodes;        // the walk array: the reference's tree in depth-first order, interior nodes that do not pay removed (rt_abi.hip, "collapse")
@@ -47,12 +81,8 @@ struct rt_frame_params {
     rt_pixel_state* state_out;            // first part of a split frame: where pixels are parked (the frame is not written)
     const rt_pixel_state* state_in;       // second part: the parked pixels (null = pixels start from their seed)
     int32_t sample_begin, sample_end;     // samples [sample_begin, sample_end) are rendered by this launch; ns is the frame's total
-    const unsigned int* heavy_pixels;     // second part: local pixel ids (lrow * nx + i) of the heavy pixels, dearest first
-    uint32_t heavy_threshold;             // pixels whose parked cost is >= this are in heavy_pixels
-    uint32_t tier1_items;                 // leading heavy_pixels entries served by tier-1 sparse workgroups
-    int32_t tier1_wgs, tier1_stride;      // tier 1: the first tier1_wgs workgroups, one pixel per tier1_stride lanes
-    uint32_t tier0_items;                 // leading heavy_pixels entries served by tier-0 workgroups (one pixel per workgroup); tier 1 follows
-    int32_t tier0_wgs;                    // tier 0: the first tier0_wgs workgroups; tier 1: the next tier1_wgs
+    const unsigned int* heavy_pixels;     // ranked launches: local pixel ids (lrow * nx + i) of the heavy pixels, dearest first
+    const rt_rank_info* rank;             // ranked launches: tier sizes left by the ranking kernels; null = no heavy list, no tiers
     uint32_t tier0_lds_offset;            // tier 0: byte offset of the workgroup's scratch (leaf list, reduction slots) in dynamic LDS
     uint64_t seed_base;
     int32_t nx, ny, ns;
@@ -63,11 +93,8 @@ struct rt_frame_params {
     int32_t local_rows;                   // rows this call renders
     int32_t tiles_x;                      // 8x8 pixel tiles per local row band
     uint32_t work_items;                  // tiles_x * tiles_y * 64
-    uint32_t heavy_items;                 // staged kernel: entries of heavy_pixels (served by sparse workgroups); 0 = none
-    int32_t sparse_wgs;                   // staged kernel: workgroups that start in sparse mode
     int32_t sparse_eager;                 // staged kernel: sparse waves run every stage as soon as one lane needs it
     int32_t sparse_priority;              // staged kernel: s_setprio level of sparse waves (0 = leave alone)
-    int32_t sparse_stride;                // staged kernel: in sparse mode only every sparse_stride-th lane takes a pixel
     int32_t steps_per_trip;               // persistent kernel: node visits between ballots
     int32_t shade_threshold;              // persistent kernel: waiting lanes that trigger shading
     int32_t leaf_threshold;               // staged kernel: lanes with an object test due that trigger the leaf pass
@@ -79,8 +106,8 @@ struct rt_frame_params {
     int32_t wf_pause_lanes;               // wavefront kernel: a wave with fewer walking lanes re-queues them once READY is empty
 };
 
-void rt_launch_collect_heavy(const rt_pixel_state* state, unsigned int n_pixels, unsigned int threshold, unsigned long long* list,
-                             unsigned int capacity, unsigned int* count, hipStream_t st);
+// the three ranking kernels of one ranked part, enqueued on `st` (no host synchronisation)
+hipError_t rt_launch_rank(const rt_rank_params& rp, hipStream_t st);
 #define RT_WF_BYTES_PER_SLOT (31 * 4 + 5 * 2)   /* 20 float + 11 int arrays, 5 u16 lists */
 
 // Launchers, one per translation unit (each returns the launch's hipError_t, including a failed

@@ -61,15 +61,24 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
     // few dearest tiles with only every fp.sparse_stride-th lane, because a lane's rays advance ~2.5x faster in a wave
     // with few live lanes and those pixels' sequential chains bound the frame time.  When that queue is drained and the
     // wave's own heavy pixels are finished it becomes an ordinary wave.  Wave-uniform.
-    bool sparse = (int)blockIdx.x < fp.sparse_wgs;
+    // tier sizes of a ranked launch, left in device memory by the ranking kernels (rt_rank.hip); wave-uniform
+    rt_rank_info rk;
+    rk.heavy_items = 0u; rk.heavy_threshold = 0xFFFFFFFFu; rk.tier0_items = 0u; rk.tier1_items = 0u;
+    rk.tier0_wgs = 0; rk.tier1_wgs = 0; rk.sparse_wgs = 0; rk.sparse_stride = 1;
+    if (fp.rank) {
+        const rt_rank_info* q = fp.rank;
+        rk.heavy_items = q->heavy_items; rk.heavy_threshold = q->heavy_threshold; rk.tier0_items = q->tier0_items; rk.tier1_items = q->tier1_items;
+        rk.tier0_wgs = q->tier0_wgs; rk.tier1_wgs = q->tier1_wgs; rk.sparse_wgs = q->sparse_wgs; rk.sparse_stride = q->sparse_stride;
+    }
+    bool sparse = (int)blockIdx.x < rk.sparse_wgs;
     // Tier-1 waves hold ONE pixel each -- the dearest pixels of the frame, whose sequential chains bound the frame time.
     // With a single live lane the state machine below is pure overhead, so they run the reference's plain loop nest
     // (as kernel A does) on pixels parked by part 1, one after another, and only then join the ordinary waves.
     // Tier-0 workgroups (spheres-only scenes) go one step further for the very dearest pixels: the whole workgroup holds
     // ONE pixel and every ray is traced by all its threads at once (trace_group()), which cuts the time per ray -- and
     // with it the sequential chain that bounds the frame and every multi-GPU partition of it -- several times over.
-    const bool tier0 = SPHERES_ONLY && LDS_MODE == 2 && (int)blockIdx.x < fp.tier0_wgs && fp.state_in != nullptr;   // workgroup-uniform
-    const bool tier1 = sparse && !tier0 && (int)blockIdx.x < fp.tier0_wgs + fp.tier1_wgs && fp.state_in != nullptr;
+    const bool tier0 = SPHERES_ONLY && LDS_MODE == 2 && (int)blockIdx.x < rk.tier0_wgs && fp.state_in != nullptr;   // workgroup-uniform
+    const bool tier1 = sparse && !tier0 && (int)blockIdx.x < rk.tier0_wgs + rk.tier1_wgs && fp.state_in != nullptr;
     if (tier0 || tier1) {
         __builtin_amdgcn_s_setprio(3);
         unsigned int* t0_scratch = reinterpret_cast<unsigned int*>(lds + fp.tier0_lds_offset);
@@ -93,12 +102,12 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                 __syncthreads();
                 idx = t0_scratch[1];
                 __syncthreads();
-                if (idx >= fp.tier0_items) break;
+                if (idx >= rk.tier0_items) break;
             } else {
                 if ((threadIdx.x & 63) == 0) idx = atomicAdd(fp.work_counter + 2, 1u);
                 idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-                if (idx >= fp.tier1_items) break;
-                idx += fp.tier0_items;
+                if (idx >= rk.tier1_items) break;
+                idx += rk.tier0_items;
             }
             const uint32_t pix = fp.heavy_pixels[idx];
             const int lrow = (int)(pix / (uint32_t)fp.nx), i = (int)(pix - (uint32_t)lrow * (uint32_t)fp.nx);
@@ -396,9 +405,9 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                         if (sparse) {
                             // heavy list (sorted by descending cost): tier 1 = its first tier1_items entries
                             // tier 2 of the heavy list (tier 1 is served by the plain loop at the top of the kernel)
-                            if (((threadIdx.x & 63) % (unsigned)fp.sparse_stride) != 0u) { alive = false; break; }
-                            const uint32_t at = fp.tier0_items + fp.tier1_items + atomicAdd(fp.work_counter + 1, 1u);
-                            if (at >= fp.heavy_items) { alive = false; break; }
+                            if (((threadIdx.x & 63) % (unsigned)rk.sparse_stride) != 0u) { alive = false; break; }
+                            const uint32_t at = rk.tier0_items + rk.tier1_items + atomicAdd(fp.work_counter + 1, 1u);
+                            if (at >= rk.heavy_items) { alive = false; break; }
                             const uint32_t pix = fp.heavy_pixels[at];
                             px_lrow = (int)(pix / (uint32_t)fp.nx); px_i = (int)(pix - (uint32_t)px_lrow * (uint32_t)fp.nx);
                             ok = true;
@@ -407,7 +416,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                             if (w >= fp.work_items) { alive = false; break; }
                             ok = work_to_pixel(fp, w, px_i, px_lrow);
                             // pixels in the heavy list belong to the sparse waves
-                            if (ok && fp.heavy_items && fp.state_in[(size_t)px_lrow * fp.nx + px_i].cost >= fp.heavy_threshold) ok = false;
+                            if (ok && rk.heavy_items && fp.state_in[(size_t)px_lrow * fp.nx + px_i].cost >= rk.heavy_threshold) ok = false;
                         }
                         if (ok) {
                             px_j = local_to_global_row(fp, px_lrow);

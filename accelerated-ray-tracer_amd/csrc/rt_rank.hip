@@ -1,20 +1,169 @@
-// rt_rank.hip -- ranking kernels of the cost-aware schedule.
+// rt_rank.hip -- the ranking between the parts of a split frame (cost-aware schedule, rt_abi.hip), on the device.
+//
+// Part 1 of a split frame parks every pixel with the rays it cost so far (rt_pixel_state.cost) and adds them up per 8x8
+// tile (tile_cost).  Before the next part starts, three small kernels turn that into the next launch's schedule:
+//   1. rt_rank_tiles_kernel   (one workgroup)  tiles ordered dearest first; cost thresholds from the mean cost per pixel;
+//   2. rt_collect_heavy_kernel (whole grid)    every pixel at or above the heavy threshold -> (cost, pixel) list;
+//   3. rt_rank_heavy_kernel   (one workgroup)  the list ordered dearest first, cut into tiers 0 / 1 / 2, workgroups per tier.
+// Everything stays in device memory (rt_rank_info), so a frame is one stream enqueue: rt_render(blocking = 0) returns
+// while the first part is still running (include/rt_abi.h).  Round 1 did this on the host with four stream
+// synchronisations per ranking.
+//
+// The two orderings are bucket sorts by one workgroup: 2048 linear cost buckets, counted and scattered through LDS
+// atomics.  Within a bucket the order is whatever the atomics give -- this is scheduling only: which wave renders a
+// pixel never changes the pixel (its samples are one XORWOW stream, picked up where the previous part left it).
 #include <hip/hip_runtime.h>
+#include <stdint.h>
+
 #include "rt_device.h"
 
-// Heavy-pixel list for the cost-aware schedule: every pixel whose prepass ray count reaches `threshold` is appended as
-// (cost << 32 | pixel); the host sorts the (short) list by descending cost.
-__global__ void rt_collect_heavy_kernel(const rt_pixel_state* state, unsigned int n_pixels, unsigned int threshold,
-                                        unsigned long long* list, unsigned int capacity, unsigned int* count) {
+namespace {
+
+enum { RANK_THREADS = 1024, RANK_BUCKETS = 2048 };
+
+// workgroup-wide max / min of a per-thread value through LDS (all threads call; result in every thread)
+__device__ unsigned int wg_reduce_max(unsigned int v, unsigned int* scratch) {
+    if (threadIdx.x == 0) *scratch = 0u;
+    __syncthreads();
+    atomicMax(scratch, v);
+    __syncthreads();
+    const unsigned int r = *scratch;
+    __syncthreads();
+    return r;
+}
+__device__ unsigned int wg_reduce_min(unsigned int v, unsigned int* scratch) {
+    if (threadIdx.x == 0) *scratch = 0xFFFFFFFFu;
+    __syncthreads();
+    atomicMin(scratch, v);
+    __syncthreads();
+    const unsigned int r = *scratch;
+    __syncthreads();
+    return r;
+}
+
+// Descending bucket sort by one workgroup: out[k] = value(i) for the items i in [0, n), dearest first.
+// hist: RANK_BUCKETS + 1 words of LDS; scratch: one word of LDS.
+template <class Key, class Val>
+__device__ void wg_bucket_sort_desc(unsigned int n, Key key, Val value, unsigned int* out, unsigned int* hist, unsigned int* scratch) {
+    unsigned int lo = 0xFFFFFFFFu, hi = 0u;
+    for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) { const unsigned int k = key(i); lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+    hi = wg_reduce_max(hi, scratch);
+    lo = wg_reduce_min(lo, scratch);
+    const unsigned long long span = (unsigned long long)(hi >= lo ? hi - lo : 0u) + 1ull;
+    for (unsigned int b = threadIdx.x; b <= RANK_BUCKETS; b += blockDim.x) hist[b] = 0u;
+    __syncthreads();
+    // bucket 0 holds the dearest items
+    auto bucket = [&](unsigned int k) -> unsigned int { return (unsigned int)(((unsigned long long)(hi - k) * RANK_BUCKETS) / span); };
+    for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[bucket(key(i))], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {   // exclusive scan; 2048 additions by one thread are a few microseconds
+        unsigned int run = 0u;
+        for (unsigned int b = 0; b < RANK_BUCKETS; ++b) { const unsigned int c = hist[b]; hist[b] = run; run += c; }
+        hist[RANK_BUCKETS] = run;
+    }
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) out[atomicAdd(&hist[bucket(key(i))], 1u)] = value(i);
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(RANK_THREADS) rt_rank_tiles_kernel(rt_rank_params rp) {
+    __shared__ unsigned int hist[RANK_BUCKETS + 1];
+    __shared__ unsigned int scratch;
+    if (threadIdx.x == 0) {
+        // cost thresholds of the heavy list and its tiers, from the mean cost per pixel so far
+        const double mean = (double)*rp.ray_counter / (double)rp.n_pixels;
+        rt_rank_info inf;
+        inf.heavy_items = 0u; inf.heavy_threshold = 0xFFFFFFFFu; inf.tier0_items = 0u; inf.tier1_items = 0u;
+        inf.tier0_wgs = 0; inf.tier1_wgs = 0; inf.sparse_wgs = 0; inf.sparse_stride = 1;
+        inf.threshold0 = (unsigned int)(mean * (double)rp.tier0_factor + 0.999);
+        inf.threshold1 = (unsigned int)(mean * (double)rp.tier1_factor + 0.999);
+        inf.collected = 0u; inf.pad = 0u;
+        if (rp.sparse_stride > 0) inf.heavy_threshold = (unsigned int)(mean * (double)rp.heavy_factor + 0.999);
+        *rp.info = inf;
+    }
+    const unsigned int* cost = rp.tile_cost;
+    wg_bucket_sort_desc(rp.n_tiles, [cost](unsigned int i) { return cost[i]; }, [](unsigned int i) { return i; }, rp.tile_order, hist, &scratch);
+}
+
+// every pixel whose parked cost reaches the heavy threshold is appended as (cost << 32 | pixel)
+__global__ void rt_collect_heavy_kernel(rt_rank_params rp) {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pixels) return;
-    const unsigned int c = state[i].cost;
+    if (i >= rp.n_pixels) return;
+    const unsigned int threshold = rp.info->heavy_threshold;
+    const unsigned int c = rp.state[i].cost;
     if (c >= threshold) {
-        const unsigned int at = atomicAdd(count, 1u);
-        if (at < capacity) list[at] = ((unsigned long long)c << 32) | i;
+        const unsigned int at = atomicAdd(&rp.info->collected, 1u);
+        if (at < rp.heavy_cap) rp.heavy_list[at] = ((unsigned long long)c << 32) | i;
     }
 }
-void rt_launch_collect_heavy(const rt_pixel_state* state, unsigned int n_pixels, unsigned int threshold, unsigned long long* list,
-                             unsigned int capacity, unsigned int* count, hipStream_t st) {
-    hipLaunchKernelGGL(rt_collect_heavy_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, st, state, n_pixels, threshold, list, capacity, count);
+
+__global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_params rp) {
+    __shared__ unsigned int hist[RANK_BUCKETS + 1];
+    __shared__ unsigned int scratch;
+    __shared__ unsigned int n_tier0, n_tier1;
+    rt_rank_info inf = *rp.info;
+    const unsigned int count = inf.collected;
+    // no list: nothing collected, more than the list holds, or so many that "heavy" has lost its meaning
+    const bool usable = rp.sparse_stride > 0 && count > 0u && count <= rp.heavy_cap && (unsigned long long)count * 8ull < (unsigned long long)rp.n_pixels;
+    if (!usable) {
+        if (threadIdx.x == 0) { inf.heavy_items = 0u; inf.heavy_threshold = 0xFFFFFFFFu; *rp.info = inf; }
+        return;
+    }
+    const unsigned long long* list = rp.heavy_list;
+    wg_bucket_sort_desc(count, [list](unsigned int i) { return (unsigned int)(list[i] >> 32); },
+                        [list](unsigned int i) { return (unsigned int)(list[i] & 0xFFFFFFFFull); }, rp.heavy_pixels, hist, &scratch);
+    if (threadIdx.x == 0) { n_tier0 = 0u; n_tier1 = 0u; }
+    __syncthreads();
+    unsigned int c0 = 0u, c1 = 0u;
+    for (unsigned int i = threadIdx.x; i < count; i += blockDim.x) {
+        const unsigned int c = (unsigned int)(list[i] >> 32);
+        c0 += c >= inf.threshold0 ? 1u : 0u;
+        c1 += c >= inf.threshold1 ? 1u : 0u;
+    }
+    if (c0) atomicAdd(&n_tier0, c0);
+    if (c1) atomicAdd(&n_tier1, c1);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    // ---- workgroups per tier.  tier 0 = one pixel per workgroup at a time, tier 1 = one per wave, tier 2 = 64 /
+    // sparse_stride live lanes per wave; each queue is served dearest first and whatever exceeds its workgroups waits.
+    const unsigned int cap_wgs = rp.max_grid * (unsigned int)rp.sparse_percent / 100u;
+    unsigned int tier0_items = rp.tier0_possible ? n_tier0 : 0u, tier1_items = n_tier1;
+    if (tier0_items > (unsigned int)rp.tier0_pixels) tier0_items = (unsigned int)rp.tier0_pixels;
+    if (tier0_items > cap_wgs / 2u) tier0_items = cap_wgs / 2u;
+    const unsigned int tier0_wgs = tier0_items;
+    tier1_items = tier1_items > tier0_items ? tier1_items - tier0_items : 0u;            // tier 1 follows tier 0 in the list
+    if (tier1_items > (unsigned int)rp.tier1_pixels) tier1_items = (unsigned int)rp.tier1_pixels;
+    unsigned int tier1_wgs = (tier1_items + rp.waves_per_wg - 1u) / rp.waves_per_wg;
+    if (tier0_wgs + tier1_wgs > cap_wgs / 2u + tier0_wgs / 2u) {
+        tier1_wgs = cap_wgs / 2u > tier0_wgs / 2u ? cap_wgs / 2u - tier0_wgs / 2u : 0u;
+        tier1_items = tier1_wgs * rp.waves_per_wg;
+        if (tier0_items + tier1_items > count) tier1_items = count - tier0_items;
+    }
+    const unsigned int tier2_items = count - tier0_items - tier1_items;
+    const unsigned int per_wg2 = rp.waves_per_wg * (64u / (unsigned int)rp.sparse_stride);
+    unsigned int tier2_wgs = (tier2_items + per_wg2 - 1u) / per_wg2;
+    if (tier0_wgs + tier1_wgs + tier2_wgs > cap_wgs) tier2_wgs = cap_wgs > tier0_wgs + tier1_wgs ? cap_wgs - tier0_wgs - tier1_wgs : 0u;
+    const unsigned int sparse_wgs = tier0_wgs + tier1_wgs + tier2_wgs;
+    unsigned int total = rp.normal_need + sparse_wgs;
+    if (total > rp.max_grid) total = rp.max_grid;
+    if (sparse_wgs > 0u && total > sparse_wgs) {
+        inf.heavy_items = count; inf.tier0_items = tier0_items; inf.tier1_items = tier1_items;
+        inf.tier0_wgs = (int32_t)tier0_wgs; inf.tier1_wgs = (int32_t)tier1_wgs; inf.sparse_wgs = (int32_t)sparse_wgs;
+        inf.sparse_stride = rp.sparse_stride;
+    } else {
+        inf.heavy_items = 0u; inf.heavy_threshold = 0xFFFFFFFFu;
+    }
+    *rp.info = inf;
+}
+
+}  // namespace
+
+hipError_t rt_launch_rank(const rt_rank_params& rp, hipStream_t st) {
+    hipLaunchKernelGGL(rt_rank_tiles_kernel, dim3(1), dim3(RANK_THREADS), 0, st, rp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rt_collect_heavy_kernel, dim3((rp.n_pixels + 255u) / 256u), dim3(256), 0, st, rp);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(rt_rank_heavy_kernel, dim3(1), dim3(RANK_THREADS), 0, st, rp);
+    return hipGetLastError();
 }
