@@ -71,7 +71,8 @@ MATERIAL_DTYPE = np.dtype([("kind", "<i4"), ("tex", "<i4"), ("fuzz", "<f4"), ("i
 # every symbol include/rt_abi.h declares
 RT_ABI_SYMBOLS = ["rt_init", "rt_shutdown", "rt_strerror", "rt_last_hip_error", "rt_last_error_detail", "rt_scene_create",
                   "rt_scene_destroy", "rt_frame_local_rows", "rt_local_to_global_row", "rt_render", "rt_frame_finish",
-                  "rt_set_option", "rt_reset_options", "rt_scene_walk_info"]
+                  "rt_set_option", "rt_reset_options", "rt_scene_walk_info", "rt_init_devices", "rt_multi_create", "rt_multi_render",
+                  "rt_multi_destroy", "rt_multi_device_count", "rt_multi_row_owner"]
 
 _rt = None
 _host = None
@@ -128,6 +129,12 @@ def rt_lib():
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RtFrameDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(RtStats)]
         L.rt_frame_finish.argtypes = [C.c_void_p, C.POINTER(RtStats)]
         L.rt_set_option.argtypes = [C.c_char_p, C.c_int]
+        L.rt_init_devices.argtypes = [C.c_int]
+        L.rt_multi_create.argtypes = [C.POINTER(RtSceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_multi_render.argtypes = [C.c_void_p, C.POINTER(RtFrameDesc), C.c_void_p, C.c_int, C.c_int, C.POINTER(RtStats)]
+        L.rt_multi_destroy.argtypes = [C.c_void_p]
+        L.rt_multi_device_count.argtypes = [C.c_void_p]
+        L.rt_multi_row_owner.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.rt_scene_walk_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _rt = L
     return _rt
@@ -296,6 +303,42 @@ class DeviceScene:
             self.close()
         except Exception:
             pass
+
+
+class MultiScene:
+    """rt_multi*: one replica of the scene per GPU, driven from this thread (rt_multi_* of include/rt_abi.h)."""
+
+    def __init__(self, host_scene: HostScene, n_gpus: int):
+        global _initialised_device
+        _check(rt_lib().rt_init_devices(n_gpus), "rt_init_devices")
+        _initialised_device = 0
+        self.host = host_scene
+        self._p = C.c_void_p()
+        _check(rt_lib().rt_multi_create(C.byref(host_scene.desc), n_gpus, C.byref(self._p)), "rt_multi_create")
+
+    def render(self, frame: RtFrameDesc, tile_rows: int = 4):
+        """The whole frame as float32[ny][nx][3] in host memory, and the summed statistics."""
+        out = np.empty((frame.ny, frame.nx, 3), np.float32)
+        stats = RtStats()
+        _check(rt_lib().rt_multi_render(self._p, C.byref(frame), out.ctypes.data, 0, tile_rows, C.byref(stats)), "rt_multi_render")
+        return out, stats
+
+    def close(self):
+        if self._p:
+            rt_lib().rt_multi_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def row_owner(global_row: int, tile_rows: int, n_gpus: int):
+    d, l = C.c_int32(0), C.c_int32(0)
+    _check(rt_lib().rt_multi_row_owner(global_row, tile_rows, n_gpus, C.byref(d), C.byref(l)), "rt_multi_row_owner")
+    return d.value, l.value
 
 
 def local_rows_to_global(frame: RtFrameDesc) -> np.ndarray:

@@ -59,6 +59,7 @@ struct rt_options {
     int sparse_wg_percent = 35;   // at most this share of the workgroups starts in sparse mode
     int bvh_collapse = 2;        // walk array (rt_scene_create): 0 = the reference's tree as is, 1 = interior nodes that do not pay
                                  // removed, decided from box surface areas, 2 = decided from pass counts measured on a small frame
+    int multi_force_rccl = 0;    // rt_multi_render: go through the RCCL gather even with one device (tests the path on a one-GPU box)
     int lpt = 1;                 // cost prepass + longest-first tile order (staged kernel, ns >= 2 * split_samples)
     int wf_slots = 0;            // 0 = as many as fit in LDS (<= 1024)
     int wf_pause_lanes = 32;
@@ -99,6 +100,8 @@ rt_status upload(const T* src, size_t count, const T** dst) {
 }
 
 }  // namespace
+
+rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_scene** out);
 
 struct rt_scene {
     int device = 0;             // the device every allocation below lives on
@@ -426,6 +429,7 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "sparse_wg_percent") { if (value < 1 || value > 100) return invalid("sparse_wg_percent: 1..100"); g_opt.sparse_wg_percent = value; }
     else if (k == "heavy_max_tiles") { if (value < 0 || value > 4096) return invalid("heavy_max_tiles: 0..4096"); g_opt.heavy_max_tiles = value; }
     else if (k == "bvh_collapse") { if (value < 0 || value > 2) return invalid("bvh_collapse: 0, 1 or 2 (read by rt_scene_create)"); g_opt.bvh_collapse = value; }
+    else if (k == "multi_force_rccl") { if (value < 0 || value > 1) return invalid("multi_force_rccl: 0 or 1"); g_opt.multi_force_rccl = value; }
     else if (k == "lpt") { if (value < 0 || value > 1) return invalid("lpt: 0 or 1"); g_opt.lpt = value; }
     else if (k == "wf_slots") { if (value < 0 || value > 4096 || (value % 64)) return invalid("wf_slots: 0 or a multiple of 64 up to 4096"); g_opt.wf_slots = value; }
     else if (k == "wf_threads") { if (value != 256 && value != 512 && value != 768 && value != 1024) return invalid("wf_threads: 256, 512, 768 or 1024"); g_opt.wf_threads = value; }
@@ -541,7 +545,24 @@ rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!out) return invalid("null output pointer");
     *out = nullptr;
     if (g_device < 0) { g_detail = "rt_init has not succeeded"; return RT_ERR_NO_DEVICE; }
-    { const rt_status ud = use_device(g_device); if (ud != RT_OK) return ud; }
+    return rt_internal_scene_create_on(g_device, d, out);
+}
+
+}  // extern "C"
+
+// ---- internals shared with rt_multi.hip
+rt_status rt_internal_init_device(int device_ordinal) {
+    const rt_status st = init_device(device_ordinal);
+    if (st == RT_OK) g_device = device_ordinal;
+    return st;
+}
+void rt_internal_set_error(rt_status st, int hip_error, const std::string& detail) { (void)st; g_last_hip_error = hip_error; g_detail = detail; }
+int rt_internal_option(const char* key) { return std::string(key) == "multi_force_rccl" ? g_opt.multi_force_rccl : 0; }
+
+rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_scene** out) {
+    if (!out) return invalid("null output pointer");
+    *out = nullptr;
+    { const rt_status ud = use_device(device); if (ud != RT_OK) return ud; }
     bool so = false, uv = false;
     int tx = 0;
     rt_status st = validate(d, so, tx, uv);
@@ -557,7 +578,7 @@ rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
 #define UPSRC_textures textures
 #define UPSRC_images images
     rt_scene* s = new rt_scene;
-    s->device = g_device;
+    s->device = device;
     memset(&s->dev, 0, sizeof(s->dev));
     memset(&s->pending_stats, 0, sizeof(s->pending_stats));
     s->spheres_only = so; s->tex_level = tx; s->need_uv = uv;
@@ -598,6 +619,8 @@ rt_status rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     *out = s;
     return RT_OK;
 }
+
+extern "C" {
 
 rt_status rt_scene_walk_info(const rt_scene* s, int32_t* nodes_reference, int32_t* nodes_walked, double* tests_before, double* tests_after) {
     if (!s) return invalid("null scene");

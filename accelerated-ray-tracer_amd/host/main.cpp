@@ -7,7 +7,10 @@
 // `--scene bouncing` is case 1, `--scene final` case 9.
 //
 //   rayTracer [--scene NAME] [--nx W --ny H] [--ns SPP] [--seed S]
-//             [--texture file.ppm] [--device N] [--list]
+//             [--texture file.ppm] [--device N] [--gpus N] [--list]
+//
+// --gpus N (N > 1) spreads the frame over the first N GPUs of the node: interleaved 4-row tiles, one scene replica
+// per device, one RCCL gather to device 0 (rt_multi_*, include/rt_abi.h).  The PPM is byte-identical for every N.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,7 +29,7 @@ static void check(rt_status st, const char* what) {
 
 int main(int argc, char** argv) {
     std::string scene_name = "bouncing", texture_path;
-    int nx = 0, ny = 0, ns = 0, device = 0;
+    int nx = 0, ny = 0, ns = 0, device = 0, gpus = 1;
     unsigned long long seed = 1984ull;
     for (int a = 1; a < argc; ++a) {
         std::string k = argv[a];
@@ -38,6 +41,7 @@ int main(int argc, char** argv) {
         else if (k == "--seed") seed = strtoull(val(), nullptr, 10);
         else if (k == "--texture") texture_path = val();
         else if (k == "--device") device = atoi(val());
+        else if (k == "--gpus") gpus = atoi(val());
         else if (k == "--list") { int n = 0; const char* const* v = rtw::scene_names(&n); for (int i = 0; i < n; ++i) printf("%s\n", v[i]); return 0; }
         else { fprintf(stderr, "unknown argument %s\n", k.c_str()); return 2; }
     }
@@ -59,10 +63,6 @@ int main(int argc, char** argv) {
     const rt_scene_desc desc = flat.desc();
 
     fprintf(stderr, "Rendering a %dx%d image in 8x8 blocks.\n", scene->nx, scene->ny);
-    check(rt_init(device), "rt_init");
-    rt_scene* dev_scene = nullptr;
-    check(rt_scene_create(&desc, &dev_scene), "rt_scene_create");
-
     rt_frame_desc f;
     memset(&f, 0, sizeof(f));
     f.nx = scene->nx; f.ny = scene->ny; f.ns = scene->ns; f.gamma = scene->gamma;
@@ -73,15 +73,26 @@ int main(int argc, char** argv) {
 
     std::vector<float> fb((size_t)scene->nx * scene->ny * 3);
     rt_stats stats;
-    check(rt_render(dev_scene, &f, fb.data(), /*fb_on_device=*/0, /*stream=*/nullptr, /*blocking=*/1, &stats), "rt_render");
+    rt_scene* dev_scene = nullptr;
+    rt_multi* multi = nullptr;
+    if (gpus > 1) {
+        check(rt_init_devices(gpus), "rt_init_devices");
+        check(rt_multi_create(&desc, gpus, &multi), "rt_multi_create");
+        check(rt_multi_render(multi, &f, fb.data(), /*fb_on_device=*/0, /*tile_rows=*/4, &stats), "rt_multi_render");
+    } else {
+        check(rt_init(device), "rt_init");
+        check(rt_scene_create(&desc, &dev_scene), "rt_scene_create");
+        check(rt_render(dev_scene, &f, fb.data(), /*fb_on_device=*/0, /*stream=*/nullptr, /*blocking=*/1, &stats), "rt_render");
+    }
     fprintf(stderr, "took %g seconds.\n", stats.ms_render * 1e-3);
-    fprintf(stderr, "{\"scene\": \"%s\", \"nx\": %d, \"ny\": %d, \"ns\": %d, \"rays\": %llu, \"ms_render\": %.3f, \"mrays_per_s\": %.1f}\n",
-            scene_name.c_str(), scene->nx, scene->ny, scene->ns, (unsigned long long)stats.rays, stats.ms_render,
+    fprintf(stderr, "{\"scene\": \"%s\", \"nx\": %d, \"ny\": %d, \"ns\": %d, \"gpus\": %d, \"rays\": %llu, \"ms_render\": %.3f, \"mrays_per_s\": %.1f}\n",
+            scene_name.c_str(), scene->nx, scene->ny, scene->ns, gpus, (unsigned long long)stats.rays, stats.ms_render,
             stats.ms_render > 0 ? (double)stats.rays / (stats.ms_render * 1e3) : 0.0);
 
     rtw::write_ppm_p3(stdout, fb.data(), scene->nx, scene->ny, scene->ppm_double_scale);
 
-    check(rt_scene_destroy(dev_scene), "rt_scene_destroy");
+    if (multi) check(rt_multi_destroy(multi), "rt_multi_destroy");
+    if (dev_scene) check(rt_scene_destroy(dev_scene), "rt_scene_destroy");
     check(rt_shutdown(), "rt_shutdown");
     return 0;
 }

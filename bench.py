@@ -35,7 +35,67 @@ sys.path.insert(0, ROOT)
 # (40.15 box tests x 32 B + 3.99 sphere tests x 32 B + ~1.1 material reads x 16 B).
 ALGO_BYTES_PER_RAY = {"bouncing": 1430.0, "random_scene": 1430.0, "book1": 1430.0, "cornell": 980.0, "final": 2500.0}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# VALU issue: 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md "Wave scheduling",
+# cycle-constants row v_fma_f32: 2 cyc throughput), max clock 2.4 GHz  ->  1228.8 G wave-instructions / s.
+N_SIMD, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0
+VALU_PEAK_GINST = N_SIMD * CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9
+VALU_MEASURED_CYCLES = 3.0   # what tools/ubench/valu_rate.hip sustains on this part at >= 2 waves per SIMD (profiles/r01_ubench_valu_rate.txt)
+LDS_PEAK_B_PER_CLK_CU = 256.0   # MI355X_MICROARCH.md, LDS table (ds_read_b64 / b128)
 TILE_ROWS = 4
+
+
+def roofline(scene, nx, ny, ns, rays_step, kernel_ms):
+    """The roofline object of the JSON line.  The binding roof of this path is VALU issue (the scene is LDS-resident and
+    compulsory HBM traffic is ~0.01 B/ray): achieved = VALU wave-instructions per second = the per-step instruction
+    count of the committed rocprofv3 PMC record (profiles/pmc_<workload>.json, made by tools/profile_bench.sh +
+    tools/pmc_to_json.py from the same bench command) / the kernel time measured live here with HIP events.  The HBM
+    figure SURVEY.md 8(d) defines (algorithmic bytes / time against 8 TB/s) is kept beside it, with the measured HBM
+    bytes as `traffic`."""
+    bpr = ALGO_BYTES_PER_RAY.get(scene, 1430.0)
+    ksec = kernel_ms * 1e-3
+    hbm_alg = rays_step * bpr / ksec / 1e9
+    key = f"{'random_scene' if scene == 'bouncing' else scene}_{nx}x{ny}_{ns}"
+    rec = None
+    path = os.path.join(ROOT, "profiles", f"pmc_{key}.json")
+    if os.path.exists(path):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            rec = None
+    hbm = {"achieved": round(hbm_alg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_alg / HBM_PEAK_GBS, 4),
+           "algorithmic_bytes_per_ray": bpr,
+           "note": "algorithmic bytes (SURVEY.md 8(d)) are served from LDS, not HBM: a fraction of the HBM roof above 1 only says the scene never leaves the CU"}
+    if rec is None:
+        r = dict(hbm)
+        r.update({"bound": "hbm", "traffic": None, "kernel_ms": round(kernel_ms, 3),
+                  "note": hbm["note"] + "; no PMC record for this workload under profiles/, so the binding VALU-issue roof is not evaluated"})
+        return r
+    c = rec["per_step"]
+    valu, lanes = c["SQ_INSTS_VALU"], c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"]
+    achieved = valu / ksec / 1e9
+    hbm_bytes = rec.get("hbm_bytes_per_step")
+    hbm.update({"traffic_bytes_per_step": hbm_bytes, "traffic_gbs": None if hbm_bytes is None else round(hbm_bytes / ksec / 1e9, 2)})
+    import hashlib, glob
+    h = hashlib.sha1()   # = `cat csrc/* | sha1sum`, what tools/profile_bench.sh recorded beside the counters
+    for fn in sorted(glob.glob(os.path.join(ROOT, "accelerated-ray-tracer_amd", "csrc", "*"))):
+        h.update(open(fn, "rb").read())
+    issue = achieved / VALU_PEAK_GINST
+    r = {"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwave-inst/s",
+         "frac": round(issue, 4), "traffic": hbm_bytes, "kernel_ms": round(kernel_ms, 3),
+         "valu": {"wave_insts_per_step": valu, "wave_insts_per_ray": round(valu / rays_step, 2),
+                  "lanes_per_inst": round(lanes, 2), "lane_utilisation": round(lanes / 64.0, 4),
+                  "issue_frac_vs_2_cycles": round(issue, 4),
+                  "issue_frac_vs_measured_3_cycles": round(issue * VALU_MEASURED_CYCLES / VALU_ISSUE_CYCLES, 4),
+                  "useful_lane_frac_of_valu_peak": round(issue * lanes / 64.0, 4),
+                  "wave_wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3) if "SQ_WAIT_ANY" in c else None,
+                  "wave_issue_stall_frac": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3) if "SQ_WAIT_INST_ANY" in c else None},
+         "lds": {"algorithmic_bytes_per_clk_per_cu": round(rays_step * bpr / (ksec * CLOCK_HZ * 256), 2), "peak": LDS_PEAK_B_PER_CLK_CU,
+                 "insts_per_step": c.get("SQ_INSTS_LDS"),
+                 "bank_conflict_share_of_lds_cycles": round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 3) if "SQ_LDS_IDX_ACTIVE" in c else None},
+         "hbm": hbm,
+         "pmc_record": f"profiles/pmc_{key}.json", "pmc_record_is_of_this_build": rec.get("csrc_sha1") == h.hexdigest()[:16],
+         "note": "instruction and byte counts per step come from the committed PMC record (rocprofv3 passes of this bench command); the time is this run's: the launches of the render kernel for one frame (three with the cost-aware schedule) plus the ranking kernels between them, HIP events on the launch stream"}
+    return r
 
 
 class RowPlan:
@@ -89,7 +149,7 @@ def parse():
     ap.add_argument("--kernel", type=int, default=None, help="0 = pixel, 1 = persistent, 2 = parked, 3 = staged (default)")
     ap.add_argument("--opt", action="append", default=[], help="rt_set_option key=value (A/B knobs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-ns", type=int, default=16, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-ns", type=int, default=48, help="spp of the bounded CPU-baseline sample (48 spp of the headline frame = ~1e8 rays, tens of core-seconds)")
     ap.add_argument("--save-ppm", default=None, help="write the last frame as ASCII PPM (rank 0)")
     return ap.parse_args()
 
@@ -97,14 +157,17 @@ def parse():
 def cpu_baseline(scene_name: str, nx: int, ny: int, ns: int) -> dict:
     """The oracle (a port of the reference's algorithm, see oracle/) timed on this box's host cores."""
     import oracle
-    threads = min(os.cpu_count() or 1, 32)
+    try:
+        threads = len(os.sched_getaffinity(0))       # the cores this process may run on (= os.cpu_count() unless restricted)
+    except AttributeError:
+        threads = os.cpu_count() or 1
     name = "bouncing" if scene_name == "random_scene" else scene_name
     sc = oracle.OracleScene(name, nx, ny)
     t0 = time.time()
     _, cnt = sc.render(ns, threads=threads, counters=True)
     dt = time.time() - t0
     return {"value": round(cnt["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{scene_name} {nx}x{ny} @ {ns} spp (same scene/seeds, reduced spp), {cnt['rays']} rays in {dt:.1f} s"}
+            "sample": f"{scene_name} {nx}x{ny} @ {ns} spp (same scene/seeds, reduced spp), {cnt['rays']} rays in {dt:.1f} s on {threads} threads (os.cpu_count() = {os.cpu_count()})"}
 
 
 def main():
@@ -192,16 +255,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         mrays = total_rays * args.steps / elapsed / 1e6
-        bpr = ALGO_BYTES_PER_RAY.get(args.scene, 1430.0)
         kms = float(np.mean(kernel_ms))
-        achieved = rays_step * bpr / (kms * 1e-3) / 1e9   # GB/s, rank 0's kernel
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(f"{args.scene}_{args.nx}x{args.ny}_{args.ns}")
-            except Exception:
-                traffic = None
         line = {
             "metric": f"Mrays/s, {args.nx}x{args.ny} {'random' if args.scene in ('random_scene', 'bouncing') else args.scene} scene @ {args.ns} spp (frame ms in ms_per_step)",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,10 +265,7 @@ def main():
                                     else f"{args.scene} (reference scene function of that name, src/main.cu)") + f" {args.nx}x{args.ny} @ {args.ns} spp, seed 1984+pixel",
                        "rays_per_frame": int(total_rays), "parallelism": f"rows{world}" if world > 1 else "single",
                        "tile_rows": TILE_ROWS if world > 1 else args.ny},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel_ms": round(kms, 3), "algorithmic_bytes_per_ray": bpr,
-                         "note": "scene is LDS-resident: algorithmic bytes are served by LDS, not HBM; kernel_ms is the device time of a step = the launches of the render kernel (three with the cost-aware schedule: samples [0,8), [8,32) and [32,ns)) plus the ranking between them, see DESIGN.md"},
+            "roofline": roofline(args.scene, args.nx, args.ny, args.ns, rays_step, kms),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.scene, args.nx, args.ny, args.cpu_ns)

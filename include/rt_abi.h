@@ -218,6 +218,27 @@ rt_status rt_render(rt_scene* scene, const rt_frame_desc* f, float* fb, int fb_o
                     void* stream, int blocking, rt_stats* stats);
 rt_status rt_frame_finish(rt_scene* scene, rt_stats* stats);
 
+/* ---- several GPUs of one node from one host thread ----
+ * The reference is single-GPU (one render<<<>>> launch, main.cu:707); these entry points are what its host function
+ * would call to spread that launch over the N GPUs of a node: rt_init_devices(N) replaces rt_init, rt_multi_create /
+ * rt_multi_render / rt_multi_destroy replace rt_scene_create / rt_render / rt_scene_destroy.  The frame is cut into
+ * tiles of `tile_rows` rows dealt round-robin to the devices (tile t -> device t % N); every device renders its rows
+ * with its own replica of the scene, one ncclGather (rccl.h:745) over xGMI brings the compact row buffers to device 0
+ * and a small kernel puts them into the reference's frame layout.  `f` describes the WHOLE frame (its tile_* fields
+ * are ignored); fb receives nx*ny*3 floats (host memory, or memory of device 0 when fb_on_device != 0).  The call
+ * returns when the frame is complete.  stats: rays / samples summed over the devices, ms_render = host wall time of
+ * the call, reserved = the slowest device's own render time in microseconds.  Pixels are bit-identical to rt_render's
+ * on one device: no ray crosses a device and the per-pixel seed is seed_base + the global pixel index. */
+typedef struct rt_multi rt_multi;
+rt_status rt_init_devices(int n_gpus);
+rt_status rt_multi_create(const rt_scene_desc* desc, int n_gpus, rt_multi** out);
+rt_status rt_multi_render(rt_multi* m, const rt_frame_desc* f, float* fb, int fb_on_device, int tile_rows, rt_stats* stats);
+rt_status rt_multi_destroy(rt_multi* m);
+int32_t rt_multi_device_count(const rt_multi* m);
+/* the row partition rt_multi_render uses: which device renders global row j and at which row of its compact buffer
+ * (the inverse of rt_local_to_global_row for tile_first = device, tile_stride = n_gpus) */
+rt_status rt_multi_row_owner(int32_t global_row, int32_t tile_rows, int32_t n_gpus, int32_t* device, int32_t* local_row);
+
 /* Tuning knobs (for A/B measurements; defaults are what ships).  Unknown keys
  * return RT_ERR_INVALID.  The knobs are process-wide; rt_reset_options()
  * restores every one of them to the shipped default.  None changes a pixel. */

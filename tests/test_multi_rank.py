@@ -68,3 +68,24 @@ def test_row_plan_matches_c_abi():
         for r in range(world):
             f = hs.frame(nx=8, ny=ny, ns=1, tile_rows=tile, tile_first=r, tile_stride=world)
             assert plan.rows_of(r) == art.local_rows_to_global(f).tolist()
+
+
+def test_c_abi_row_partition_round_trips():
+    """rt_multi_render (single process, N devices) deals 4-row tiles round-robin; its un-interleave kernel uses
+    rt_multi_row_owner, which must be the inverse of rt_local_to_global_row for every row of every rank -- the same
+    partition bench.py's RowPlan describes."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import accelerated_ray_tracer_amd as art
+    hs = art.HostScene("two_spheres")
+    for ny, tile, world in [(800, 4, 8), (1080, 4, 8), (101, 8, 3), (7, 4, 2), (600, 600, 1), (5, 1, 4)]:
+        plan = bench.RowPlan(ny, tile, world)
+        seen = np.zeros(ny, np.int32)
+        for r in range(world):
+            f = hs.frame(nx=8, ny=ny, ns=1, tile_rows=tile, tile_first=r, tile_stride=world)
+            rows = art.local_rows_to_global(f)
+            assert rows.tolist() == plan.rows_of(r)
+            for k, j in enumerate(rows):
+                assert art.row_owner(int(j), tile, world) == (r, k)
+                seen[j] += 1
+        assert (seen == 1).all()

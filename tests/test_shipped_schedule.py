@@ -5,6 +5,8 @@ split 32 / presplit 8, automatic tier sizing, device-side ranking) -- exactly wh
 bits with the CPU oracle on row bands (a whole 1200x800 @ 500 frame is 1.0e9 rays; a band of 8 rows is ~1e7, seconds
 on the host), plus the ray counts of those bands.  Reference path: render_init + render, src/main.cu:96-133.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -151,3 +153,38 @@ def test_nonblocking_render_returns_before_the_frame_is_done(gpu):
         assert torch.equal(buf.view(torch.int32), ref.view(torch.int32))
     finally:
         ds.close()
+
+
+@pytest.mark.parametrize("force_rccl", [0, 1])
+def test_multi_device_entry_points_on_one_gpu(gpu, force_rccl):
+    """rt_multi_* (one host thread, N devices, RCCL gather + un-interleave) with N = 1, which is all a one-GPU box can run:
+    plain (no gather) and with the gather forced through RCCL (multi_force_rccl: ncclCommInitAll on one device,
+    ncclGather of the 4-row-tile buffer, un-interleave kernel).  Both must reproduce rt_render's frame bit for bit."""
+    hs = gpu.HostScene("random_scene", 240, 136)
+    gpu.reset_options()
+    ds = gpu.DeviceScene(hs)
+    ref, st_ref = ds.render(hs.frame(ns=64))
+    ds.close()
+    gpu.set_option("multi_force_rccl", force_rccl)
+    ms = gpu.MultiScene(hs, 1)
+    try:
+        fb, st = ms.render(hs.frame(ns=64), tile_rows=4)
+    finally:
+        ms.close()
+        gpu.reset_options()
+    assert st.rays == st_ref.rays and st.samples == st_ref.samples and st.local_rows == 136
+    assert bits_equal(fb, ref)
+
+
+def test_raytracer_gpus_flag(gpu, tmp_path):
+    """`rayTracer --gpus 1` is byte-identical to the plain run (the multi-device path is only taken for N > 1), and
+    asking for more devices than the box has fails with the reference's exit code 99 instead of rendering something else."""
+    import subprocess
+    exe = os.path.join(gpu.LIB_DIR, "rayTracer")
+    base = subprocess.run([exe, "--scene", "bouncing", "--nx", "64", "--ny", "40", "--ns", "4"], capture_output=True, timeout=120)
+    one = subprocess.run([exe, "--scene", "bouncing", "--nx", "64", "--ny", "40", "--ns", "4", "--gpus", "1"], capture_output=True, timeout=120)
+    assert base.returncode == 0 and one.returncode == 0 and base.stdout == one.stdout
+    import torch
+    too_many = torch.cuda.device_count() + 1
+    bad = subprocess.run([exe, "--scene", "bouncing", "--nx", "64", "--ny", "40", "--ns", "4", "--gpus", str(too_many)], capture_output=True, timeout=120)
+    assert bad.returncode == 99, bad.stderr.decode()

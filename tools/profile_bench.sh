@@ -6,6 +6,8 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+# which sources these counters belong to (bench.py compares it with the tree it runs from)
+cat accelerated-ray-tracer_amd/csrc/* | sha1sum | cut -c1-16 > $out/csrc_sha1.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py "$@" --no-cpu-baseline > $out/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $out/pmc_sq1 -- python3 bench.py "$@" --no-cpu-baseline > $out/pmc_sq1.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --output-format csv -d $out/pmc_sq2 -- python3 bench.py "$@" --no-cpu-baseline > $out/pmc_sq2.log 2>&1
