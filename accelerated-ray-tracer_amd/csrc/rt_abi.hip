@@ -37,8 +37,8 @@ struct rt_options {
     int lds_mode = -1;          // -1 = choose from the scene size
     int steps_per_trip = 12;
     int shade_threshold = 32;
-    int wg_per_cu = 2;
-    int threads = RT_PERSISTENT_THREADS;
+    int wg_per_cu = 0;          // workgroups per CU of the staged kernel; 0 = per kernel family (2 x 512 lean, 3 x 256 otherwise)
+    int threads = 0;            // workgroup size of the staged kernel; 0 = what the kernel family's register budget calls for
     int leaf_threshold = 8;     // lanes with an object test due that trigger the leaf pass (they keep walking meanwhile)
     int diel_threshold = 2;
     int box_threshold = 8;
@@ -59,6 +59,7 @@ struct rt_options {
     int sparse_wg_percent = 35;   // at most this share of the workgroups starts in sparse mode
     int bvh_collapse = 2;        // walk array (rt_scene_create): 0 = the reference's tree as is, 1 = interior nodes that do not pay
                                  // removed, decided from box surface areas, 2 = decided from pass counts measured on a small frame
+    int scan_nodes = 24;         // scenes whose walk array has at most this many nodes are scanned in lockstep (lds_mode 4); 0 = never
     int multi_force_rccl = 0;    // rt_multi_render: go through the RCCL gather even with one device (tests the path on a one-GPU box)
     int lpt = 1;                 // cost prepass + longest-first tile order (staged kernel, ns >= 2 * split_samples)
     int wf_slots = 0;            // 0 = as many as fit in LDS (<= 1024)
@@ -429,17 +430,18 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "sparse_wg_percent") { if (value < 1 || value > 100) return invalid("sparse_wg_percent: 1..100"); g_opt.sparse_wg_percent = value; }
     else if (k == "heavy_max_tiles") { if (value < 0 || value > 4096) return invalid("heavy_max_tiles: 0..4096"); g_opt.heavy_max_tiles = value; }
     else if (k == "bvh_collapse") { if (value < 0 || value > 2) return invalid("bvh_collapse: 0, 1 or 2 (read by rt_scene_create)"); g_opt.bvh_collapse = value; }
+    else if (k == "scan_nodes") { if (value < 0 || value > 64) return invalid("scan_nodes: 0..64"); g_opt.scan_nodes = value; }
     else if (k == "multi_force_rccl") { if (value < 0 || value > 1) return invalid("multi_force_rccl: 0 or 1"); g_opt.multi_force_rccl = value; }
     else if (k == "lpt") { if (value < 0 || value > 1) return invalid("lpt: 0 or 1"); g_opt.lpt = value; }
     else if (k == "wf_slots") { if (value < 0 || value > 4096 || (value % 64)) return invalid("wf_slots: 0 or a multiple of 64 up to 4096"); g_opt.wf_slots = value; }
     else if (k == "wf_threads") { if (value != 256 && value != 512 && value != 768 && value != 1024) return invalid("wf_threads: 256, 512, 768 or 1024"); g_opt.wf_threads = value; }
     else if (k == "wf_wg_per_cu") { if (value < 1 || value > 8) return invalid("wf_wg_per_cu: 1..8"); g_opt.wf_wg_per_cu = value; }
     else if (k == "wf_pause_lanes") { if (value < 1 || value > 64) return invalid("wf_pause_lanes: 1..64"); g_opt.wf_pause_lanes = value; }
-    else if (k == "threads") { if (value != 64 && value != 128 && value != 256 && value != 512) return invalid("threads: 64, 128, 256 or 512"); g_opt.threads = value; }
-    else if (k == "lds_mode") { if (value < -1 || value > 3) return invalid("lds_mode: -1..3"); g_opt.lds_mode = value; }
+    else if (k == "threads") { if (value != 0 && (value < 64 || value > 768 || (value % 64))) return invalid("threads: 0 (per kernel family) or a multiple of 64 up to 768 (512 for the lean spheres-only kernels)"); g_opt.threads = value; }
+    else if (k == "lds_mode") { if (value < -1 || value > 4) return invalid("lds_mode: -1..4"); g_opt.lds_mode = value; }
     else if (k == "steps_per_trip") { if (value < 1 || value > 64) return invalid("steps_per_trip: 1..64"); g_opt.steps_per_trip = value; }
     else if (k == "shade_threshold") { if (value < 1 || value > 64) return invalid("shade_threshold: 1..64"); g_opt.shade_threshold = value; }
-    else if (k == "wg_per_cu") { if (value < 1 || value > 8) return invalid("wg_per_cu: 1..8"); g_opt.wg_per_cu = value; }
+    else if (k == "wg_per_cu") { if (value < 0 || value > 8) return invalid("wg_per_cu: 0 (per kernel family) .. 8"); g_opt.wg_per_cu = value; }
     else return invalid("unknown option");
     return RT_OK;
 }
@@ -731,23 +733,26 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     fp.box_threshold = g_opt.box_threshold; fp.medium_threshold = g_opt.medium_threshold;
     fp.newpath_threshold = g_opt.newpath_threshold;
 
-    // LDS residency: nodes + spheres if two workgroups still fit a CU, else nodes only, else none
+    // LDS residency: nodes + spheres in every workgroup of a CU if they fit that many times (2 workgroups for the lean
+    // spheres-only kernels, 3 otherwise: see the workgroup shapes below), else once (one big workgroup per CU), else nodes only
     int lds_mode = g_opt.lds_mode;
-    const size_t budget2 = g_lds_per_cu / 2 - 1024, budget1 = g_lds_per_cu - 2048;
+    const bool lean_family = s->spheres_only && s->tex_level < 2;
+    const int want_per_cu = g_opt.wg_per_cu > 0 ? g_opt.wg_per_cu : (lean_family ? 2 : 3);
+    const size_t budget2 = g_lds_per_cu / (size_t)want_per_cu - 1024, budget1 = g_lds_per_cu - 2048;
     if (lds_mode < 0) {
         // (lds_mode 3 -- materials and textures in LDS too -- is selectable but measured no faster: profiles/r01_sweep34)
         if (s->node_bytes + s->sphere_bytes <= budget2) lds_mode = 2;
-        else if (s->node_bytes <= budget2) lds_mode = 1;
         else if (s->node_bytes + s->sphere_bytes <= budget1) lds_mode = 2;
         else if (s->node_bytes <= budget1) lds_mode = 1;
         else lds_mode = 0;
     }
-    if (lds_mode == 3 && g_opt.kernel != RT_KERNEL_STAGED) lds_mode = 2;
+    if (g_opt.lds_mode < 0 && g_opt.kernel == RT_KERNEL_STAGED && g_opt.scan_nodes > 0 && s->dev.n_nodes <= g_opt.scan_nodes) lds_mode = 4;   // lockstep scan of a tiny scene
+    if (lds_mode >= 3 && g_opt.kernel != RT_KERNEL_STAGED) lds_mode = 2;
     if (g_opt.kernel == RT_KERNEL_PIXEL) lds_mode = 0;   // the cross-check kernel reads the scene through L1/L2
     size_t lds_bytes = 0;
-    if (lds_mode >= 1) lds_bytes += s->node_bytes;
-    if (lds_mode >= 2) lds_bytes += s->sphere_bytes;
-    if (lds_mode >= 3) lds_bytes += s->shade_bytes;
+    if (lds_mode >= 1 && lds_mode <= 3) lds_bytes += s->node_bytes;
+    if (lds_mode >= 2 && lds_mode <= 3) lds_bytes += s->sphere_bytes;
+    if (lds_mode == 3) lds_bytes += s->shade_bytes;
     if (lds_bytes > budget1) return invalid("requested lds_mode does not fit the CU's LDS");
 
     // the wavefront kernel covers spheres-only scenes with inline/solid/checker textures and frames whose
@@ -807,11 +812,24 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         block = dim3(256);
         grid = dim3((fp.work_items + 255u) / 256u);
     } else {
-        block = dim3(kernel == RT_KERNEL_PIXEL ? 256 : g_opt.threads);
-        int per_cu = g_opt.wg_per_cu;
-        if (lds_bytes) { const int fit = (int)(g_lds_per_cu / (lds_bytes + 512)); if (fit < per_cu) per_cu = fit < 1 ? 1 : fit; }
+        // workgroup shape per kernel family (register budgets: launch bounds, rt_device.h): the lean spheres-only
+        // kernels 2 x 512 threads per CU (4 waves per SIMD), the others 3 x 256 (3 waves per SIMD; workgroups of four
+        // waves, one per SIMD -- 2 x 384 threads is the same occupancy and measured 1.4x slower on the Cornell box)
+        const bool lean = s->spheres_only && s->tex_level < 2;
+        const int fam_max_threads = lean ? RT_LEAN_MAX_THREADS : RT_HEAVY_MAX_THREADS;
+        const int lds_fit = lds_bytes ? (int)(g_lds_per_cu / (lds_bytes + 512)) : 8;
+        int per_cu = g_opt.wg_per_cu > 0 ? g_opt.wg_per_cu : (lean ? 2 : 3);
+        int threads = g_opt.threads > 0 ? g_opt.threads : (lean ? 512 : 256);
+        if (g_opt.wg_per_cu <= 0 && g_opt.threads <= 0 && lds_fit < per_cu) {
+            // the scene's LDS image does not fit that many times: one workgroup with all the CU's waves shares one image
+            per_cu = 1; threads = fam_max_threads;
+        }
+        if (lds_fit < per_cu) per_cu = lds_fit < 1 ? 1 : lds_fit;
+        if (threads > fam_max_threads) threads = fam_max_threads;
+        if (threads < 64) threads = 64;
+        block = dim3((unsigned)threads);
         unsigned want = (unsigned)(g_num_cu * per_cu);
-        const unsigned need = (fp.work_items + g_opt.threads - 1) / g_opt.threads;
+        const unsigned need = (fp.work_items + (unsigned)threads - 1) / (unsigned)threads;
         grid = dim3(want < need ? want : need);
         per_cu_resident = per_cu;
     }

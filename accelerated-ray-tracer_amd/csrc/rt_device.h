@@ -6,10 +6,18 @@
 
 #include "../../include/rt_abi.h"
 
-#define RT_PERSISTENT_THREADS 512
-#ifndef RT_PARKED_MIN_WAVES
-#define RT_PARKED_MIN_WAVES 4   // waves per SIMD the lean staged kernel (spheres-only, solid / checker colours) is register-limited to allow
+#define RT_PERSISTENT_THREADS 512   // default workgroup size of the staged kernel
+// Register budgets of the staged kernel families, as launch bounds (threads per workgroup the code may be launched
+// with, waves per SIMD it must leave room for).  "Lean" = spheres-only scenes without procedural / image textures (the
+// headline kernel): 94 VGPRs once the double-precision transcendentals are out of line, but more than 4 waves per SIMD
+// only slow the dearest pixels' chains down (profiles/r02g_occupancy_sweep.log: 2 x 640 threads 131 ms, 2 x 512 110 ms).
+// Everything else (quads / boxes / media, Perlin / image textures) fits 168 VGPRs without spilling: 3 waves per SIMD.
+#ifndef RT_LEAN_MIN_WAVES
+#define RT_LEAN_MIN_WAVES 4
 #endif
+#define RT_LEAN_MAX_THREADS 512
+#define RT_HEAVY_MAX_THREADS 768
+#define RT_HEAVY_MIN_WAVES 3
 
 // kernel ids keep their round-1 numbers (1 = persistent and 2 = parked were the steps between 0 and 3; removed)
 enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_STAGED = 3, RT_KERNEL_WAVEFRONT = 4 };

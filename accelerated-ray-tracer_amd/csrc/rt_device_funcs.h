@@ -65,12 +65,12 @@ DEV f3 fma3(f3 t, f3 v, f3 a) { return mk3(fmaf(t.x, v.x, a.x), fmaf(t.y, v.y, a
 DEV f3 unit_vector(f3 v) { return sdiv(v, length(v)); }
 
 // correctly rounded fp32 transcendentals via double
-DEV float cr_pow(float x, float y) { return (float)pow((double)x, (double)y); }
+__device__ __attribute__((noinline)) float cr_pow(float x, float y) { return (float)pow((double)x, (double)y); }
 DEV float cr_pow5(float x) { double d = (double)x; return (float)(d * d * d * d * d); }
-DEV float cr_log(float x) { return (float)log((double)x); }
-DEV float cr_sin(float x) { return (float)sin((double)x); }
-DEV float cr_acos(float x) { return (float)acos((double)x); }
-DEV float cr_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __attribute__((noinline)) float cr_log(float x) { return (float)log((double)x); }
+__device__ __attribute__((noinline)) float cr_sin(float x) { return (float)sin((double)x); }
+__device__ __attribute__((noinline)) float cr_acos(float x) { return (float)acos((double)x); }
+__device__ __attribute__((noinline)) float cr_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
 
 // ------------------------------------------------------------------ ray (ray.cuh:5-21)
 // The ray's time is a double in the reference but is only ever consumed
@@ -344,7 +344,7 @@ DEV float perlin_noise(f3 p) {
             }
     return accum;
 }
-DEV float perlin_turb(f3 p, int depth) {
+__device__ __attribute__((noinline)) float perlin_turb(f3 p, int depth) {
     float accum = 0.0f, weight = 1.0f;
     f3 temp = p;
     for (int i = 0; i < depth; ++i) {
@@ -563,7 +563,7 @@ DEV SceneView stage_scene(const rt_scene_dev& sd, unsigned char* lds) {
     SceneView v;
     v.nodes = sd.nodes; v.spheres = sd.spheres; v.quads = sd.quads; v.boxes = sd.boxes; v.instances = sd.instances;
     v.media = sd.media; v.materials = sd.materials; v.textures = sd.textures; v.images = sd.images; v.n_nodes = sd.n_nodes;
-    if (LDS_MODE >= 1) {
+    if (LDS_MODE >= 1 && LDS_MODE <= 3) {
         float4* dst = reinterpret_cast<float4*>(lds);
         const float4* src = reinterpret_cast<const float4*>(sd.nodes);
         const int n16 = sd.n_nodes * 2;

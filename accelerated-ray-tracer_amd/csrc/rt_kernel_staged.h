@@ -34,11 +34,16 @@
 #endif
 
 template <bool SPHERES_ONLY, int TEX, bool NEED_UV, int LDS_MODE>
-__global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 2) ? RT_PARKED_MIN_WAVES : 2) rt_render_staged_kernel(rt_scene_dev sd, rt_frame_params fp) {
+__global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREADS : RT_HEAVY_MAX_THREADS, (SPHERES_ONLY && TEX < 2) ? RT_LEAN_MIN_WAVES : RT_HEAVY_MIN_WAVES) rt_render_staged_kernel(rt_scene_dev sd, rt_frame_params fp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef RT_DIAG
     unsigned long long diag_local[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    // LDS_MODE 4 = "scan": a scene of a few nodes (Cornell box: 11 after the collapse) is not walked lane by lane.  All
+    // lanes that have a ray go through the depth-first array together, node by node; node and object records have
+    // wave-uniform addresses (scalar cache, no LDS), the object kind is a scalar branch, and a lane only carries the index
+    // below which it skips (a failed interior box).  Same tests against the same limits in the same order as the walk.
+    constexpr bool SCAN = LDS_MODE == 4;
     const SceneView sc = stage_scene<LDS_MODE>(sd, lds);
     const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
     const int n_nodes = sc.n_nodes;
@@ -172,6 +177,29 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
 
     for (;;) {
         DIAG_ADD(0, 1);
+        if (SCAN) {
+            // ---------------- stages A + B, scan form (see LDS_MODE 4 above)
+            const bool scanning = (unsigned)node < (unsigned)n_nodes;      // a ray set up in stage F and not yet traced
+            if (__ballot(scanning) != 0ull) {
+                const bool ref_form = __ballot(scanning && !finite_inv) != 0ull;   // a zero direction component somewhere: aabb.cuh's own form for all
+                int resume = 0;                                            // this lane skips nodes below this index
+                for (int k = 0; k < n_nodes; ++k) {
+                    const float4 a = nodes4[2 * k], b = nodes4[2 * k + 1];
+                    const int32_t prim = __builtin_amdgcn_readfirstlane(__float_as_int(b.w));
+                    const int skip = __builtin_amdgcn_readfirstlane(__float_as_int(a.w));
+                    const bool active = scanning && k >= resume;
+                    DIAG_ADD(1, 1); DIAG_ADD(2, __popcll(__ballot(active)));
+                    const bool pass = active && (ref_form ? slab_test(a, b, cur.o, inv, tmin, best.t) : slab_test_finite(a, b, cur.o, inv, tmin, best.t));
+                    if (prim < 0) {
+                        if (active && !pass) resume = skip;
+                    } else if (__ballot(pass) != 0ull) {
+                        DIAG_ADD(3, 1); DIAG_ADD(4, __popcll(__ballot(pass)));
+                        if (pass) leaf_test<SPHERES_ONLY>(sc, prim, cur, tmin, best);
+                    }
+                }
+                if (scanning) node = ST_DONE;
+            }
+        } else {
         // ---------------- stage A: node steps
         // A lane whose box test passes at a leaf does not stop there: it notes the leaf (`pend`) and walks on with the
         // limit it has; only a second leaf while the first is still due stops it (node = ~resume, `parked` = that leaf).
@@ -229,8 +257,8 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
             const unsigned long long due_mask = __ballot(cand >= 0);
             const bool nobody_steps = __ballot((unsigned)node < (unsigned)n_nodes) == 0ull;
             const int live_b = __popcll(__ballot(node != ST_DEAD));
-            DIAG_ADD(3, due_mask != 0ull); DIAG_ADD(4, __popcll(due_mask));
             if (due_mask != 0ull && (nobody_steps || sparse || __popcll(due_mask) >= 1 + ((fp.leaf_threshold - 1) * live_b >> 6))) {
+                DIAG_ADD(3, 1); DIAG_ADD(4, __popcll(due_mask));
                 int kind = -1;
                 int32_t prim = -1;
                 bool box_ok = false;
@@ -286,6 +314,7 @@ __global__ void __launch_bounds__(RT_PERSISTENT_THREADS, (SPHERES_ONLY && TEX < 
                 if (nobody_steps && __ballot((unsigned)node < (unsigned)n_nodes) == 0ull && __ballot(pend >= 0 || node < 0) != 0ull) continue;
             }
             break;
+        }
         }
         // a finished walk that hit nothing (main.cu:57-68) needs no stage: add the background and end the path now
         if (node == ST_DONE && pend < 0 && best.prim < 0) {
@@ -485,7 +514,8 @@ static hipError_t rt_launch_staged_family(int lds_mode, const rt_scene_dev& sd, 
         hipLaunchKernelGGL((rt_render_staged_kernel<SO, TX, UV, LM>), grid, block, lds, st, sd, fp);                      \
         return hipGetLastError();                                                                                         \
     } while (0)
-    if (lds_mode >= 3) RT_STAGED_LAUNCH(3);
+    if (lds_mode == 4) RT_STAGED_LAUNCH(4);
+    if (lds_mode == 3) RT_STAGED_LAUNCH(3);
     if (lds_mode == 2) RT_STAGED_LAUNCH(2);
     if (lds_mode == 1) RT_STAGED_LAUNCH(1);
     RT_STAGED_LAUNCH(0);

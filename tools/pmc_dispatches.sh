@@ -6,7 +6,7 @@ tag=$1; ns=$2; shift; shift
 out=gpurun_out/pmcd_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $out/pmc -- python3 tools/sweep.py --ns $ns --rounds 1 "$@" > $out/sweep.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $out/pmc -- python3 tools/sweep.py $SWEEP_ARGS --ns $ns --rounds 1 "$@" > $out/sweep.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
