@@ -49,11 +49,14 @@ struct rt_options {
     int tier0_auto = 1;          // size the tiers from the share of the frame this call renders (see rank_pixels); 0 = the knobs as set
     int tier0_pixels = 128;      // dearest pixels served one per WORKGROUP (tier 0, spheres-only scenes); 0 = off
     int tier0_factor_x10 = 70;   // ... among those costing at least this multiple (x10) of the mean
+    int resplit_samples = 0;     // a second ranking: samples [split, resplit) run with tiers ranked on `split` samples, the rest ranked on `resplit` (0 = off)
     int presplit_samples = 8;    // a first, shorter look: samples [presplit, split) already run with tiers ranked on it (0 = off)
     int tier1_factor_x10 = 70;   // tier 1 = heavy pixels costing >= this/10 x the mean
     int tier1_pixels = 256;      // heavy pixels served with one live lane per wave
-    int heavy_factor_x10 = 40;   // a pixel is "heavy" when its prepass ray count is >= this/10 x the mean
+    int heavy_factor_x10 = 20;   // a pixel is listed ("heavy") when its cost so far is >= this/10 x the mean ...
+    int sparse_factor_x10 = 40;  // ... and goes to a sparse wave (tier 2) from this/10 x the mean; below, ordinary lanes take it first (tier 3)
     int heavy_max_tiles = 0;     // 0 = as many as the sparse workgroups hold at once
+    int semi_stride = 0;         // lanes per pixel in the workgroups serving tier 3 (0 = ordinary lanes take tier 3 first)
     int sparse_priority = 3;
     int sparse_eager = 0;
     int sparse_wg_percent = 35;   // at most this share of the workgroups starts in sparse mode
@@ -417,14 +420,17 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "diel_threshold") { if (value < 1 || value > 64) return invalid("diel_threshold: 1..64"); g_opt.diel_threshold = value; }
     else if (k == "newpath_threshold") { if (value < 1 || value > 64) return invalid("newpath_threshold: 1..64"); g_opt.newpath_threshold = value; }
     else if (k == "sparse_stride") { if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return invalid("sparse_stride: 0, 2, 4, ... 64"); g_opt.sparse_stride = value; }
+    else if (k == "sparse_factor_x10") { if (value < 10 || value > 1000) return invalid("sparse_factor_x10: 10..1000"); g_opt.sparse_factor_x10 = value; }
     else if (k == "heavy_factor_x10") { if (value < 10 || value > 1000) return invalid("heavy_factor_x10: 10..1000"); g_opt.heavy_factor_x10 = value; }
     else if (k == "tier0_auto") { if (value < 0 || value > 1) return invalid("tier0_auto: 0 or 1"); g_opt.tier0_auto = value; }
     else if (k == "tier0_pixels") { if (value < 0 || value > 4096) return invalid("tier0_pixels: 0..4096"); g_opt.tier0_pixels = value; }
     else if (k == "tier0_factor_x10") { if (value < 10 || value > 10000) return invalid("tier0_factor_x10: 10..10000"); g_opt.tier0_factor_x10 = value; }
     else if (k == "presplit_samples") { if (value < 0 || value > 4096) return invalid("presplit_samples: 0..4096"); g_opt.presplit_samples = value; }
+    else if (k == "resplit_samples") { if (value < 0 || value > 65536) return invalid("resplit_samples: 0..65536"); g_opt.resplit_samples = value; }
     else if (k == "split_samples") { if (value < 1 || value > 4096) return invalid("split_samples: 1..4096"); g_opt.split_samples = value; }
     else if (k == "tier1_factor_x10") { if (value < 10 || value > 10000) return invalid("tier1_factor_x10: 10..10000"); g_opt.tier1_factor_x10 = value; }
     else if (k == "tier1_pixels") { if (value < 0 || value > 8192) return invalid("tier1_pixels: 0..8192"); g_opt.tier1_pixels = value; }
+    else if (k == "semi_stride") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return invalid("semi_stride: 0, 1, 2, 4 or 8"); g_opt.semi_stride = value; }
     else if (k == "sparse_eager") { if (value < 0 || value > 1) return invalid("sparse_eager: 0 or 1"); g_opt.sparse_eager = value; }
     else if (k == "sparse_priority") { if (value < 0 || value > 3) return invalid("sparse_priority: 0..3"); g_opt.sparse_priority = value; }
     else if (k == "sparse_wg_percent") { if (value < 1 || value > 100) return invalid("sparse_wg_percent: 1..100"); g_opt.sparse_wg_percent = value; }
@@ -495,7 +501,7 @@ rt_status measure_pass_counts(rt_scene* s, std::vector<double>& pass, double& ra
     unsigned long long r = 0;
     do {
         if ((e = hipMemset(d_pass, 0, (size_t)n * sizeof(unsigned int))) != hipSuccess) break;
-        if ((e = hipMemset(s->d_ray_counter, 0, 256)) != hipSuccess) break;
+        if ((e = hipMemset(s->d_ray_counter, 0, RT_COUNTER_BYTES)) != hipSuccess) break;
         if ((e = rt_launch_pixel(s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, dim3((fp.work_items + 255u) / 256u), dim3(256), nullptr)) != hipSuccess) break;
         if ((e = hipDeviceSynchronize()) != hipSuccess) break;
         if ((e = hipMemcpy(h.data(), d_pass, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost)) != hipSuccess) break;
@@ -609,7 +615,7 @@ rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_sce
     s->node_bytes = (size_t)d->n_nodes * sizeof(rt_node);
     s->sphere_bytes = (size_t)d->n_spheres * sizeof(rt_sphere);
     hipError_t e;
-    if ((e = hipMalloc((void**)&s->d_ray_counter, 256)) != hipSuccess || (e = hipMalloc((void**)&s->d_work_counter, 64)) != hipSuccess ||
+    if ((e = hipMalloc((void**)&s->d_ray_counter, RT_COUNTER_BYTES)) != hipSuccess || (e = hipMalloc((void**)&s->d_work_counter, 64)) != hipSuccess ||
         (e = hipEventCreate(&s->ev_start)) != hipSuccess || (e = hipEventCreate(&s->ev_stop)) != hipSuccess) {
         g_last_hip_error = (int)e; g_detail = "allocating per-frame resources failed";
         rt_scene_destroy(s);
@@ -679,6 +685,22 @@ rt_status rt_debug_counters(rt_scene* s, unsigned long long* out16) {
     if (!s || !out16) return invalid("null argument");
     { const rt_status ud = use_device(s->device); if (ud != RT_OK) return ud; }
     HIPCHK(hipMemcpy(out16, s->d_ray_counter + 1, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+// Diagnostic builds: when the waves of the LAST launch ended, as two histograms of RT_DIAG_BINS bins of 1 ms after the first
+// wave's start (ordinary waves, then waves that started in sparse / tier mode).
+rt_status rt_debug_wave_ends(rt_scene* s, unsigned long long* out, int n) {
+    if (!s || !out || n < 0 || n > 2 * RT_DIAG_BINS) return invalid("bad argument");
+    { const rt_status ud = use_device(s->device); if (ud != RT_OK) return ud; }
+    HIPCHK(hipMemcpy(out, s->d_ray_counter + RT_DIAG_HIST_SLOT, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+// ... and per wave of the last launch, two words about the lane that ran out of work last: (done_us << 32 | fetch_us of its last
+// pixel), (source queue << 60 | started sparse << 59 | local pixel id)
+rt_status rt_debug_wave_last(rt_scene* s, unsigned long long* out, int n_waves) {
+    if (!s || !out || n_waves < 0 || n_waves > RT_DIAG_MAX_WAVES) return invalid("bad argument");
+    { const rt_status ud = use_device(s->device); if (ud != RT_OK) return ud; }
+    HIPCHK(hipMemcpy(out, s->d_ray_counter + RT_DIAG_WAVE_SLOT, (size_t)2 * n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -867,7 +889,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     fp.sample_begin = 0; fp.sample_end = f->ns;
     const size_t n_tiles = (size_t)fp.tiles_x * (size_t)tiles_y;
     const size_t n_pixels = (size_t)local_rows * (size_t)f->nx;
-    enum { RT_HEAVY_CAP = 32768 };
+    enum { RT_HEAVY_CAP = 262144 };
     s->ranked_frame = false;
     HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 256, stream));
     if (g_opt.lpt && kernel == RT_KERNEL_STAGED && f->ns >= 2 * g_opt.split_samples && n_tiles >= 64 && n_pixels < (1ull << 31)) {
@@ -896,12 +918,12 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             // is best with no tier 0 (it is throughput-bound), half a frame with a moderate one, a quarter or less with
             // every pixel above twice the mean on tier-0 workgroups.
             int e_tier0_pixels = g_opt.tier0_pixels, e_tier0_factor = g_opt.tier0_factor_x10, e_tier1_pixels = g_opt.tier1_pixels,
-                e_heavy_factor = g_opt.heavy_factor_x10, e_sparse_percent = g_opt.sparse_wg_percent;
+                e_heavy_factor = g_opt.heavy_factor_x10, e_sparse_factor = g_opt.sparse_factor_x10, e_sparse_percent = g_opt.sparse_wg_percent;
             if (g_opt.tier0_auto) {
                 const double share = (double)n_pixels / ((double)f->nx * (double)f->ny);
                 if (share > 0.75) e_tier0_pixels = 0;
-                else if (share > 0.375) { e_tier0_pixels = 1024; e_tier0_factor = 40; e_tier1_pixels = 256; e_heavy_factor = 35; e_sparse_percent = 50; }
-                else { e_tier0_pixels = 4096; e_tier0_factor = 20; e_tier1_pixels = 0; e_heavy_factor = 20; e_sparse_percent = 80; }
+                else if (share > 0.375) { e_tier0_pixels = 1024; e_tier0_factor = 40; e_tier1_pixels = 256; e_heavy_factor = 20; e_sparse_factor = 35; e_sparse_percent = 50; }
+                else { e_tier0_pixels = 4096; e_tier0_factor = 20; e_tier1_pixels = 0; e_heavy_factor = 20; e_sparse_factor = 20; e_sparse_percent = 80; }
             }
             rt_rank_params rp;
             memset(&rp, 0, sizeof(rp));
@@ -911,10 +933,12 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             rp.max_grid = max_grid; rp.waves_per_wg = block.x / 64u;
             rp.normal_need = (uint32_t)((q.work_items + block.x - 1) / block.x);
             rp.sparse_stride = (g_opt.sparse_stride > 0 && block.x >= 64) ? g_opt.sparse_stride : 0;
+            rp.semi_stride = g_opt.semi_stride;
             rp.sparse_percent = e_sparse_percent;
             rp.tier0_possible = tier0_possible ? 1 : 0;
             rp.tier0_pixels = e_tier0_pixels; rp.tier1_pixels = e_tier1_pixels;
-            rp.heavy_factor = (float)e_heavy_factor / 10.0f; rp.tier1_factor = (float)g_opt.tier1_factor_x10 / 10.0f; rp.tier0_factor = (float)e_tier0_factor / 10.0f;
+            if (e_sparse_factor < e_heavy_factor) e_sparse_factor = e_heavy_factor;
+            rp.heavy_factor = (float)e_heavy_factor / 10.0f; rp.sparse_factor = (float)e_sparse_factor / 10.0f; rp.tier1_factor = (float)g_opt.tier1_factor_x10 / 10.0f; rp.tier0_factor = (float)e_tier0_factor / 10.0f;
             HIPCHK(rt_launch_rank(rp, stream));
             q.tile_order = s->d_tile_order; q.heavy_pixels = s->d_heavy_pixels; q.rank = s->d_rank;
             unsigned total = rp.normal_need + (rp.sparse_stride > 0 ? max_grid * (unsigned)e_sparse_percent / 100u : 0u);
@@ -942,8 +966,23 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
             HIPCHK(launch_render(kernel, lds_mode, s, p2, grid2, block, lds_bytes, stream));
         }
-        // ---- part 2: samples [S0, ns), ranked on the first S0 samples
-        fp.state_in = s->d_state; fp.sample_begin = g_opt.split_samples;
+        // ---- part 1c (optional): samples [S0, S1), ranked on the first S0 samples; the last part is then ranked again on
+        // S1 samples.  A pixel's cost over 32 samples is a noisy estimate of its cost over 500 (paths through glass are
+        // heavy-tailed): pixels that look cheap and are not start late and end the frame (tools/diag_wave_ends.py).
+        int last_begin = g_opt.split_samples;
+        if (g_opt.resplit_samples > g_opt.split_samples && f->ns >= 2 * g_opt.resplit_samples) {
+            rt_frame_params p3 = fp;
+            dim3 grid3 = grid;
+            p3.sample_begin = g_opt.split_samples; p3.sample_end = g_opt.resplit_samples;
+            p3.state_in = s->d_state; p3.state_out = s->d_state; p3.tile_cost = s->d_tile_cost;
+            const rt_status st2 = rank_pixels(p3, grid3);
+            if (st2 != RT_OK) return st2;
+            HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
+            HIPCHK(launch_render(kernel, lds_mode, s, p3, grid3, block, lds_bytes, stream));
+            last_begin = g_opt.resplit_samples;
+        }
+        // ---- part 2: samples [S1 or S0, ns), ranked on everything rendered so far
+        fp.state_in = s->d_state; fp.sample_begin = last_begin;
         const rt_status st3 = rank_pixels(fp, grid);
         if (st3 != RT_OK) return st3;
         out.workgroups = (int)grid.x;
@@ -951,6 +990,11 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     }
     out.reserved = 0;
     HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));   // the ray counter keeps part 1's rays
+#ifdef RT_DIAG
+    // wave-end histograms of the frame's last launch only (rt_debug_wave_ends)
+    HIPCHK(hipMemsetAsync(s->d_ray_counter + RT_DIAG_T0_SLOT, 0xFF, 8, stream));
+    HIPCHK(hipMemsetAsync(s->d_ray_counter + RT_DIAG_HIST_SLOT, 0, (size_t)(2 * RT_DIAG_BINS + 7 + 2 * RT_DIAG_MAX_WAVES) * 8, stream));
+#endif
     HIPCHK(launch_render(kernel, lds_mode, s, fp, grid, block, lds_bytes, stream));
     HIPCHK(hipEventRecord(s->ev_stop, stream));
     s->frame_pending = true;

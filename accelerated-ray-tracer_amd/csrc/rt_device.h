@@ -20,6 +20,10 @@
 #define RT_HEAVY_MIN_WAVES 3
 
 // kernel ids keep their round-1 numbers (1 = persistent and 2 = parked were the steps between 0 and 3; removed)
+// the statistics block behind rt_frame_params.ray_counter (64-bit words): [0] rays, [1..16] stage counters and [32..] the
+// wave-end histograms of diagnostic builds (-DRT_DIAG), [31] the wavefront kernel's iteration-cap flag
+enum { RT_DIAG_BINS = 192, RT_DIAG_T0_SLOT = 32, RT_DIAG_HIST_SLOT = 33, RT_DIAG_WAVE_SLOT = 33 + 2 * 192 + 7, RT_DIAG_MAX_WAVES = 8192,
+       RT_COUNTER_BYTES = (33 + 2 * 192 + 7 + 2 * 8192) * 8 };   // + per wave: two words about the lane that finished last
 enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_STAGED = 3, RT_KERNEL_WAVEFRONT = 4 };
 
 // A pixel parked at a sample boundary (split frames): XORWOW state, colour sum, rays traced so far.
@@ -36,13 +40,17 @@ struct rt_rank_info {
     uint32_t heavy_items;        // entries of heavy_pixels (dearest first); 0 = no list
     uint32_t heavy_threshold;    // pixels whose parked cost is >= this are in the list (ordinary waves skip them)
     uint32_t tier0_items;        // leading entries served one per WORKGROUP (tier 0)
-    uint32_t tier1_items;        // following entries served one per WAVE (tier 1); the rest go to sparse waves (tier 2)
+    uint32_t tier1_items;        // following entries served one per WAVE (tier 1)
+    uint32_t tier2_items;        // following entries served by sparse waves (tier 2); the REST of the list (tier 3) is taken by
+                                 // ordinary lanes before anything else, so that every dear pixel's chain starts at once
     int32_t tier0_wgs, tier1_wgs;   // workgroups [0, tier0_wgs) are tier 0, the next tier1_wgs tier 1
     int32_t sparse_wgs;          // workgroups [0, sparse_wgs) start in sparse mode (tiers 0, 1, 2)
     int32_t sparse_stride;       // sparse waves: every sparse_stride-th lane takes a pixel
+    int32_t semi_wgs;            // the next semi_wgs workgroups serve tier 3 with every semi_stride-th lane (0: ordinary lanes take tier 3)
+    int32_t semi_stride;
     uint32_t threshold0, threshold1;   // costs that qualify for tier 0 / tier 1 (set with heavy_threshold by the first ranking kernel)
+    uint32_t threshold2;         // cost that qualifies for the sparse waves (tier 2)
     uint32_t collected;          // entries rt_collect_heavy_kernel appended (may exceed the capacity: then there is no list)
-    uint32_t pad;
 };
 
 // constants of one ranking (host-filled kernel argument)
@@ -57,10 +65,12 @@ struct rt_rank_params {
     uint32_t n_pixels, n_tiles, heavy_cap;
     uint32_t max_grid, waves_per_wg, normal_need;
     int32_t sparse_stride;               // 0 = no heavy list at all
+    int32_t semi_stride;                 // lanes per pixel in the workgroups that serve tier 3 (0 = ordinary lanes take tier 3 first)
     int32_t sparse_percent;              // at most this share of max_grid starts in sparse mode
     int32_t tier0_possible;              // tier 0 needs a spheres-only scene resident in LDS
     int32_t tier0_pixels, tier1_pixels;  // caps on the tier sizes
-    float heavy_factor, tier1_factor, tier0_factor;   // cost thresholds as multiples of the mean cost per pixel
+    float heavy_factor, sparse_factor, tier1_factor, tier0_factor;   // cost thresholds as multiples of the mean cost per pixel:
+                                         // >= heavy: in the list at all; >= sparse: tier 2; >= tier1 / tier0: those tiers
 };
 
 // device-resident scene: the rt_scene_desc arrays after upload

@@ -38,6 +38,10 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef RT_DIAG
     unsigned long long diag_local[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long diag_t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    if ((threadIdx.x & 63) == 0) atomicMin(fp.ray_counter + RT_DIAG_T0_SLOT, diag_t_start);
+    unsigned long long diag_fetch_t = 0ull, diag_done_t = 0ull;   // when this lane took its last pixel / ran out of work
+    unsigned int diag_last_px = 0u, diag_last_src = 0u;          // that pixel, and where it came from (0 tile, 2 sparse list, 3 tier 3)
 #endif
     // LDS_MODE 4 = "scan": a scene of a few nodes (Cornell box: 11 after the collapse) is not walked lane by lane.  All
     // lanes that have a ray go through the depth-first array together, node by node; node and object records have
@@ -61,6 +65,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     int32_t pend = -1;           // leaf node whose box passed during the walk and whose object test is still due
     float cur_a = 1.f;           // dot(d, d) of the current ray (sphere.cuh:58), hoisted out of the sphere tests
     bool have_pixel = false, first = true, finite_inv = true;
+    bool tier3_open = true;      // this lane has not yet seen the end of the tier-3 queue
     unsigned int rays = 0, rays_at_pixel_start = 0;
     // Sparse mode (see rt_abi.hip, "heavy tiles"): the first fp.sparse_wgs workgroups start by serving the queue of the
     // few dearest tiles with only every fp.sparse_stride-th lane, because a lane's rays advance ~2.5x faster in a wave
@@ -68,14 +73,20 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     // wave's own heavy pixels are finished it becomes an ordinary wave.  Wave-uniform.
     // tier sizes of a ranked launch, left in device memory by the ranking kernels (rt_rank.hip); wave-uniform
     rt_rank_info rk;
-    rk.heavy_items = 0u; rk.heavy_threshold = 0xFFFFFFFFu; rk.tier0_items = 0u; rk.tier1_items = 0u;
-    rk.tier0_wgs = 0; rk.tier1_wgs = 0; rk.sparse_wgs = 0; rk.sparse_stride = 1;
+    rk.heavy_items = 0u; rk.heavy_threshold = 0xFFFFFFFFu; rk.tier0_items = 0u; rk.tier1_items = 0u; rk.tier2_items = 0u;
+    rk.tier0_wgs = 0; rk.tier1_wgs = 0; rk.sparse_wgs = 0; rk.sparse_stride = 1; rk.semi_wgs = 0; rk.semi_stride = 1;
     if (fp.rank) {
         const rt_rank_info* q = fp.rank;
         rk.heavy_items = q->heavy_items; rk.heavy_threshold = q->heavy_threshold; rk.tier0_items = q->tier0_items; rk.tier1_items = q->tier1_items;
+        rk.tier2_items = q->tier2_items; rk.semi_wgs = q->semi_wgs; rk.semi_stride = q->semi_stride;
         rk.tier0_wgs = q->tier0_wgs; rk.tier1_wgs = q->tier1_wgs; rk.sparse_wgs = q->sparse_wgs; rk.sparse_stride = q->sparse_stride;
     }
     bool sparse = (int)blockIdx.x < rk.sparse_wgs;
+    // "semi" workgroups come next: tier 3 (listed pixels too cheap for a sparse wave) with every semi_stride-th lane live
+    bool semi = !sparse && (int)blockIdx.x < rk.sparse_wgs + rk.semi_wgs;
+#ifdef RT_DIAG
+    const bool diag_was_sparse = sparse;
+#endif
     // Tier-1 waves hold ONE pixel each -- the dearest pixels of the frame, whose sequential chains bound the frame time.
     // With a single live lane the state machine below is pure overhead, so they run the reference's plain loop nest
     // (as kernel A does) on pixels parked by part 1, one after another, and only then join the ordinary waves.
@@ -435,19 +446,34 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                             // heavy list (sorted by descending cost): tier 1 = its first tier1_items entries
                             // tier 2 of the heavy list (tier 1 is served by the plain loop at the top of the kernel)
                             if (((threadIdx.x & 63) % (unsigned)rk.sparse_stride) != 0u) { alive = false; break; }
-                            const uint32_t at = rk.tier0_items + rk.tier1_items + atomicAdd(fp.work_counter + 1, 1u);
-                            if (at >= rk.heavy_items) { alive = false; break; }
+                            const uint32_t k2 = atomicAdd(fp.work_counter + 1, 1u);
+                            if (k2 >= rk.tier2_items) { alive = false; break; }
+                            const uint32_t at = rk.tier0_items + rk.tier1_items + k2;
                             const uint32_t pix = fp.heavy_pixels[at];
+                            px_lrow = (int)(pix / (uint32_t)fp.nx); px_i = (int)(pix - (uint32_t)px_lrow * (uint32_t)fp.nx);
+                            ok = true;
+                        } else if (tier3_open && (semi || rk.semi_wgs == 0)) {
+                            // tier 3: listed pixels too cheap for a sparse wave start at once, dearest first -- on the semi
+                            // workgroups' live lanes, or (no semi workgroups) on any ordinary lane before it takes a tile
+                            if (semi && ((threadIdx.x & 63) % (unsigned)rk.semi_stride) != 0u) { alive = false; break; }
+                            const uint32_t k3 = atomicAdd(fp.work_counter + 4, 1u);
+                            const uint32_t first3 = rk.tier0_items + rk.tier1_items + rk.tier2_items;
+                            if (first3 + k3 >= rk.heavy_items) { tier3_open = false; if (semi) { alive = false; break; } continue; }
+                            const uint32_t pix = fp.heavy_pixels[first3 + k3];
                             px_lrow = (int)(pix / (uint32_t)fp.nx); px_i = (int)(pix - (uint32_t)px_lrow * (uint32_t)fp.nx);
                             ok = true;
                         } else {
                             const uint32_t w = atomicAdd(fp.work_counter, 1u);
                             if (w >= fp.work_items) { alive = false; break; }
                             ok = work_to_pixel(fp, w, px_i, px_lrow);
-                            // pixels in the heavy list belong to the sparse waves
+                            // pixels in the heavy list belong to the tiers
                             if (ok && rk.heavy_items && fp.state_in[(size_t)px_lrow * fp.nx + px_i].cost >= rk.heavy_threshold) ok = false;
                         }
                         if (ok) {
+#ifdef RT_DIAG
+                            diag_fetch_t = __builtin_amdgcn_s_memrealtime(); diag_last_px = (unsigned int)px_lrow * (unsigned int)fp.nx + (unsigned int)px_i;
+                            diag_last_src = sparse ? 2u : (tier3_open ? 3u : 0u);
+#endif
                             px_j = local_to_global_row(fp, px_lrow);
                             if (fp.state_in) {   // second part of a split frame: pick the pixel up where the first part left it
                                 const rt_pixel_state st = fp.state_in[(size_t)px_lrow * fp.nx + px_i];
@@ -469,6 +495,9 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                         node = ST_SETUP;
                     } else {
                         node = ST_DEAD;
+#ifdef RT_DIAG
+                        diag_done_t = __builtin_amdgcn_s_memrealtime();
+#endif
                     }
                 }
             }
@@ -486,8 +515,8 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
             }
         } else if (force) {
             // nothing walking, nothing waiting: every lane is ST_DEAD
-            if (!sparse) break;
-            sparse = false;                         // heavy queue drained and our heavy pixels done: become an ordinary wave
+            if (!sparse && !semi) break;
+            sparse = false; semi = false;           // our queue is drained and our pixels are done: become an ordinary wave
             __builtin_amdgcn_s_setprio(0);
             node = ST_NEWPATH; first = true; have_pixel = false;
         }
@@ -496,7 +525,25 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     for (int off = 32; off > 0; off >>= 1) r64 += __shfl_down(r64, off, 64);
     if ((threadIdx.x & 63) == 0 && r64) atomicAdd(fp.ray_counter, r64);
 #ifdef RT_DIAG
-    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 16; ++k) atomicAdd(fp.ray_counter + 1 + k, diag_local[k]);
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 16; ++k) atomicAdd(fp.ray_counter + 1 + k, diag_local[k]);
+        const unsigned long long t0 = *reinterpret_cast<volatile unsigned long long*>(fp.ray_counter + RT_DIAG_T0_SLOT);
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        unsigned long long bin = now > t0 ? (now - t0) / 100000ull : 0ull;   // 1 ms bins
+        if (bin >= (unsigned long long)RT_DIAG_BINS) bin = RT_DIAG_BINS - 1;
+        atomicAdd(fp.ray_counter + RT_DIAG_HIST_SLOT + (diag_was_sparse ? RT_DIAG_BINS : 0) + bin, 1ull);
+    }
+    {   // the lane that ran out of work last: when it took its last pixel, which pixel, from which queue
+        unsigned long long best_done = diag_done_t;
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(best_done, off, 64); best_done = o > best_done ? o : best_done; }
+        const unsigned long long t0 = *reinterpret_cast<volatile unsigned long long*>(fp.ray_counter + RT_DIAG_T0_SLOT);
+        const unsigned int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (diag_done_t == best_done && best_done != 0ull && wave_id < (unsigned int)RT_DIAG_MAX_WAVES) {
+            const unsigned long long f_us = diag_fetch_t > t0 ? (diag_fetch_t - t0) / 100ull : 0ull, d_us = best_done > t0 ? (best_done - t0) / 100ull : 0ull;
+            fp.ray_counter[RT_DIAG_WAVE_SLOT + 2 * wave_id] = (d_us << 32) | (f_us & 0xFFFFFFFFull);
+            fp.ray_counter[RT_DIAG_WAVE_SLOT + 2 * wave_id + 1] = ((unsigned long long)diag_last_src << 60) | ((unsigned long long)(diag_was_sparse ? 1u : 0u) << 59) | diag_last_px;
+        }
+    }
 #endif
 }
 

@@ -73,11 +73,12 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_tiles_kernel(rt_rank_par
         // cost thresholds of the heavy list and its tiers, from the mean cost per pixel so far
         const double mean = (double)*rp.ray_counter / (double)rp.n_pixels;
         rt_rank_info inf;
-        inf.heavy_items = 0u; inf.heavy_threshold = 0xFFFFFFFFu; inf.tier0_items = 0u; inf.tier1_items = 0u;
-        inf.tier0_wgs = 0; inf.tier1_wgs = 0; inf.sparse_wgs = 0; inf.sparse_stride = 1;
+        inf.heavy_items = 0u; inf.heavy_threshold = 0xFFFFFFFFu; inf.tier0_items = 0u; inf.tier1_items = 0u; inf.tier2_items = 0u;
+        inf.tier0_wgs = 0; inf.tier1_wgs = 0; inf.sparse_wgs = 0; inf.sparse_stride = 1; inf.semi_wgs = 0; inf.semi_stride = 1;
         inf.threshold0 = (unsigned int)(mean * (double)rp.tier0_factor + 0.999);
         inf.threshold1 = (unsigned int)(mean * (double)rp.tier1_factor + 0.999);
-        inf.collected = 0u; inf.pad = 0u;
+        inf.threshold2 = (unsigned int)(mean * (double)rp.sparse_factor + 0.999);
+        inf.collected = 0u;
         if (rp.sparse_stride > 0) inf.heavy_threshold = (unsigned int)(mean * (double)rp.heavy_factor + 0.999);
         *rp.info = inf;
     }
@@ -100,7 +101,7 @@ __global__ void rt_collect_heavy_kernel(rt_rank_params rp) {
 __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_params rp) {
     __shared__ unsigned int hist[RANK_BUCKETS + 1];
     __shared__ unsigned int scratch;
-    __shared__ unsigned int n_tier0, n_tier1;
+    __shared__ unsigned int n_tier0, n_tier1, n_tier2;
     rt_rank_info inf = *rp.info;
     const unsigned int count = inf.collected;
     // no list: nothing collected, more than the list holds, or so many that "heavy" has lost its meaning
@@ -112,16 +113,18 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
     const unsigned long long* list = rp.heavy_list;
     wg_bucket_sort_desc(count, [list](unsigned int i) { return (unsigned int)(list[i] >> 32); },
                         [list](unsigned int i) { return (unsigned int)(list[i] & 0xFFFFFFFFull); }, rp.heavy_pixels, hist, &scratch);
-    if (threadIdx.x == 0) { n_tier0 = 0u; n_tier1 = 0u; }
+    if (threadIdx.x == 0) { n_tier0 = 0u; n_tier1 = 0u; n_tier2 = 0u; }
     __syncthreads();
-    unsigned int c0 = 0u, c1 = 0u;
+    unsigned int c0 = 0u, c1 = 0u, c2 = 0u;
     for (unsigned int i = threadIdx.x; i < count; i += blockDim.x) {
         const unsigned int c = (unsigned int)(list[i] >> 32);
         c0 += c >= inf.threshold0 ? 1u : 0u;
         c1 += c >= inf.threshold1 ? 1u : 0u;
+        c2 += c >= inf.threshold2 ? 1u : 0u;
     }
     if (c0) atomicAdd(&n_tier0, c0);
     if (c1) atomicAdd(&n_tier1, c1);
+    if (c2) atomicAdd(&n_tier2, c2);
     __syncthreads();
     if (threadIdx.x != 0) return;
     // ---- workgroups per tier.  tier 0 = one pixel per workgroup at a time, tier 1 = one per wave, tier 2 = 64 /
@@ -139,15 +142,29 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
         tier1_items = tier1_wgs * rp.waves_per_wg;
         if (tier0_items + tier1_items > count) tier1_items = count - tier0_items;
     }
-    const unsigned int tier2_items = count - tier0_items - tier1_items;
+    // tier 2 = what is left of the pixels at or above the sparse threshold; tier 3 = the rest of the list
+    unsigned int tier2_items = n_tier2 > tier0_items + tier1_items ? n_tier2 - tier0_items - tier1_items : 0u;
+    if (tier0_items + tier1_items + tier2_items > count) tier2_items = count - tier0_items - tier1_items;
     const unsigned int per_wg2 = rp.waves_per_wg * (64u / (unsigned int)rp.sparse_stride);
     unsigned int tier2_wgs = (tier2_items + per_wg2 - 1u) / per_wg2;
     if (tier0_wgs + tier1_wgs + tier2_wgs > cap_wgs) tier2_wgs = cap_wgs > tier0_wgs + tier1_wgs ? cap_wgs - tier0_wgs - tier1_wgs : 0u;
+    if (tier2_wgs == 0u) tier2_items = 0u;   // nobody to serve them sparsely: they join tier 3
     const unsigned int sparse_wgs = tier0_wgs + tier1_wgs + tier2_wgs;
-    unsigned int total = rp.normal_need + sparse_wgs;
+    // tier 3 on workgroups of their own with every semi_stride-th lane live (a lane's rays advance faster the fewer lanes
+    // its wave has), as many as hold the whole tier at once
+    unsigned int semi_wgs = 0u;
+    if (rp.semi_stride > 0) {
+        const unsigned int tier3_items = count - tier0_items - tier1_items - tier2_items;
+        const unsigned int per_wg3 = rp.waves_per_wg * (64u / (unsigned int)rp.semi_stride);
+        semi_wgs = (tier3_items + per_wg3 - 1u) / per_wg3;
+        const unsigned int room = cap_wgs > sparse_wgs ? cap_wgs - sparse_wgs : 0u;
+        if (semi_wgs > room) semi_wgs = room;
+    }
+    unsigned int total = rp.normal_need + sparse_wgs + semi_wgs;
     if (total > rp.max_grid) total = rp.max_grid;
-    if (sparse_wgs > 0u && total > sparse_wgs) {
-        inf.heavy_items = count; inf.tier0_items = tier0_items; inf.tier1_items = tier1_items;
+    if (total > sparse_wgs + semi_wgs) {
+        inf.semi_wgs = (int32_t)semi_wgs; inf.semi_stride = rp.semi_stride > 0 ? rp.semi_stride : 1;
+        inf.heavy_items = count; inf.tier0_items = tier0_items; inf.tier1_items = tier1_items; inf.tier2_items = tier2_items;
         inf.tier0_wgs = (int32_t)tier0_wgs; inf.tier1_wgs = (int32_t)tier1_wgs; inf.sparse_wgs = (int32_t)sparse_wgs;
         inf.sparse_stride = rp.sparse_stride;
     } else {

@@ -180,7 +180,11 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
                 (4, {"wf_pause_lanes": 1, "steps_per_trip": 3}),
                 (0, {"lds_mode": 0}), (3, {"bvh_collapse": 0}), (3, {"bvh_collapse": 1}), (3, {"bvh_collapse": 1, "leaf_threshold": 1, "steps_per_trip": 3}),
                 (3, {"bvh_collapse": 0, "leaf_threshold": 64, "steps_per_trip": 20}), (3, {"leaf_threshold": 1}), (3, {"leaf_threshold": 33, "steps_per_trip": 2}),
-                (4, {"bvh_collapse": 0}), (4, {"bvh_collapse": 1})]
+                (4, {"bvh_collapse": 0}), (4, {"bvh_collapse": 1}),
+                # tier 3 (listed pixels below the sparse threshold): on ordinary lanes, on semi workgroups, none; a second ranking
+                (3, {"split_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 30, "semi_stride": 0}), (3, {"split_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 30, "semi_stride": 2}),
+                (3, {"split_samples": 2, "presplit_samples": 1, "heavy_factor_x10": 12, "sparse_factor_x10": 20, "semi_stride": 4, "tier1_pixels": 0}),
+                (3, {"split_samples": 1, "resplit_samples": 3, "heavy_factor_x10": 10, "sparse_factor_x10": 15}), (3, {"split_samples": 2, "resplit_samples": 3, "presplit_samples": 1, "semi_stride": 8, "heavy_factor_x10": 10})]
     for kernel, opts in variants:
         fb, st = render(gpu, hs, kernel, opts, ns=6)
         assert st.rays == st0.rays, (kernel, opts)
