@@ -59,6 +59,7 @@ struct rt_options {
     int semi_stride = 0;         // lanes per pixel in the workgroups serving tier 3 (0 = ordinary lanes take tier 3 first)
     int sparse_priority = 3;
     int sparse_eager = 0;
+    int sparse_work_percent = 5;  // tiers 0-2 hold at most this share of the frame's work (rays so far); dearer-than-average pixels beyond it go to tier 3
     int sparse_wg_percent = 35;   // at most this share of the workgroups starts in sparse mode
     int bvh_collapse = 2;        // walk array (rt_scene_create): 0 = the reference's tree as is, 1 = interior nodes that do not pay
                                  // removed, decided from box surface areas, 2 = decided from pass counts measured on a small frame
@@ -433,6 +434,7 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "semi_stride") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return invalid("semi_stride: 0, 1, 2, 4 or 8"); g_opt.semi_stride = value; }
     else if (k == "sparse_eager") { if (value < 0 || value > 1) return invalid("sparse_eager: 0 or 1"); g_opt.sparse_eager = value; }
     else if (k == "sparse_priority") { if (value < 0 || value > 3) return invalid("sparse_priority: 0..3"); g_opt.sparse_priority = value; }
+    else if (k == "sparse_work_percent") { if (value < 0 || value > 100) return invalid("sparse_work_percent: 0..100"); g_opt.sparse_work_percent = value; }
     else if (k == "sparse_wg_percent") { if (value < 1 || value > 100) return invalid("sparse_wg_percent: 1..100"); g_opt.sparse_wg_percent = value; }
     else if (k == "heavy_max_tiles") { if (value < 0 || value > 4096) return invalid("heavy_max_tiles: 0..4096"); g_opt.heavy_max_tiles = value; }
     else if (k == "bvh_collapse") { if (value < 0 || value > 2) return invalid("bvh_collapse: 0, 1 or 2 (read by rt_scene_create)"); g_opt.bvh_collapse = value; }
@@ -602,7 +604,23 @@ rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_sce
     UP(boxes, d->n_boxes);
     UP(instances, d->n_instances);
     UP(media, d->n_media);
-    UP(materials, d->n_materials);
+    {   // materials: `pad` tells resolve_hit() whether the material's texture reads the hit's (u, v)
+        std::vector<rt_material> mats(d->materials, d->materials + d->n_materials);
+        auto reads_uv = [&](int tex) -> bool {
+            if (tex < 0) return false;
+            const rt_texture& t = d->textures[tex];
+            if (t.kind == RT_TEX_IMAGE || t.kind == RT_TEX_UV_OFFSET) return true;
+            if (t.kind == RT_TEX_CHECKER) {
+                const int ka = d->textures[t.a].kind, kb = d->textures[t.b].kind;   // validate(): checker children are plain textures
+                return ka == RT_TEX_IMAGE || kb == RT_TEX_IMAGE;
+            }
+            return false;
+        };
+        for (rt_material& m : mats) m.pad = reads_uv(m.tex) ? 1.0f : 0.0f;
+        st = upload(mats.data(), mats.size(), &s->dev.materials);
+        if (st != RT_OK) { rt_scene_destroy(s); return st; }
+        s->allocs.push_back(const_cast<void*>(static_cast<const void*>(s->dev.materials)));
+    }
     UP(textures, d->n_textures);
     UP(images, d->image_bytes);
 #undef UP
@@ -935,6 +953,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             rp.sparse_stride = (g_opt.sparse_stride > 0 && block.x >= 64) ? g_opt.sparse_stride : 0;
             rp.semi_stride = g_opt.semi_stride;
             rp.sparse_percent = e_sparse_percent;
+            rp.sparse_work_percent = g_opt.sparse_work_percent;
             rp.tier0_possible = tier0_possible ? 1 : 0;
             rp.tier0_pixels = e_tier0_pixels; rp.tier1_pixels = e_tier1_pixels;
             if (e_sparse_factor < e_heavy_factor) e_sparse_factor = e_heavy_factor;

@@ -67,6 +67,7 @@ struct rt_rank_params {
     int32_t sparse_stride;               // 0 = no heavy list at all
     int32_t semi_stride;                 // lanes per pixel in the workgroups that serve tier 3 (0 = ordinary lanes take tier 3 first)
     int32_t sparse_percent;              // at most this share of max_grid starts in sparse mode
+    int32_t sparse_work_percent;         // ... and tiers 0-2 together hold at most this share of the frame's rays so far
     int32_t tier0_possible;              // tier 0 needs a spheres-only scene resident in LDS
     int32_t tier0_pixels, tier1_pixels;  // caps on the tier sizes
     float heavy_factor, sparse_factor, tier1_factor, tier0_factor;   // cost thresholds as multiples of the mean cost per pixel:

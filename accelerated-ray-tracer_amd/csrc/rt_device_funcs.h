@@ -285,7 +285,9 @@ DEV HitRec resolve_hit(const SceneView& sc, const Ray& r, const HitInfo& h) {
         const f3 cc = fma3(q.tm, ld3(s.vel), ld3(s.c0));
         rec.p = ray_at(q, h.t);
         rec.n = sdiv(rec.p - cc, s.radius);
-        if (NEED_UV) sphere_uv(rec.n, rec.u, rec.v);
+        // sphere uv (acos / atan2, sphere.cuh:42-49) only where something reads it: rt_scene_create marks the materials
+        // whose texture looks at (u, v) -- an image or a uv-offset texture, directly or under a checker -- in `pad`
+        if (NEED_UV && sc.materials[s.mat].pad != 0.0f) sphere_uv(rec.n, rec.u, rec.v);
         rec.mat = s.mat;
     } else {                                                // quad.cuh:71-88
         const rt_quad qd = sc.quads[idx];

@@ -405,7 +405,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                 ran_stage = true;
                 DIAG_ADD(7, 1); DIAG_ADD(8, n_diel);
                 if (node == ST_DIEL) {
-                    const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, cur, best);
+                    const HitRec rec = resolve_hit<SPHERES_ONLY, false>(sc, cur, best);   // a dielectric reads no (u, v)
                     const f3 dir = dielectric_direction(cur.d, rec.n, sc.materials[rec.mat].ior, g);
                     ++bounce;
                     if (bounce >= 50) node = ST_NEWPATH;

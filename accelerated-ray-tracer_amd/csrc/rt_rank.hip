@@ -43,8 +43,11 @@ __device__ unsigned int wg_reduce_min(unsigned int v, unsigned int* scratch) {
 
 // Descending bucket sort by one workgroup: out[k] = value(i) for the items i in [0, n), dearest first.
 // hist: RANK_BUCKETS + 1 words of LDS; scratch: one word of LDS.
+// On return hist[b] = number of items in buckets 0..b (the dearest b + 1 buckets) and *hi_out / *span_out describe the
+// buckets: bucket b holds costs in (hi - (b + 1) * span / RANK_BUCKETS, hi - b * span / RANK_BUCKETS].
 template <class Key, class Val>
-__device__ void wg_bucket_sort_desc(unsigned int n, Key key, Val value, unsigned int* out, unsigned int* hist, unsigned int* scratch) {
+__device__ void wg_bucket_sort_desc(unsigned int n, Key key, Val value, unsigned int* out, unsigned int* hist, unsigned int* scratch,
+                                    unsigned int* hi_out = nullptr, unsigned long long* span_out = nullptr) {
     unsigned int lo = 0xFFFFFFFFu, hi = 0u;
     for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) { const unsigned int k = key(i); lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
     hi = wg_reduce_max(hi, scratch);
@@ -63,6 +66,7 @@ __device__ void wg_bucket_sort_desc(unsigned int n, Key key, Val value, unsigned
     }
     __syncthreads();
     for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) out[atomicAdd(&hist[bucket(key(i))], 1u)] = value(i);
+    if (threadIdx.x == 0) { if (hi_out) *hi_out = hi; if (span_out) *span_out = span; }
     __syncthreads();
 }
 
@@ -101,7 +105,8 @@ __global__ void rt_collect_heavy_kernel(rt_rank_params rp) {
 __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_params rp) {
     __shared__ unsigned int hist[RANK_BUCKETS + 1];
     __shared__ unsigned int scratch;
-    __shared__ unsigned int n_tier0, n_tier1, n_tier2;
+    __shared__ unsigned int n_tier0, n_tier1, n_tier2, sort_hi;
+    __shared__ unsigned long long sort_span;
     rt_rank_info inf = *rp.info;
     const unsigned int count = inf.collected;
     // no list: nothing collected, more than the list holds, or so many that "heavy" has lost its meaning
@@ -112,7 +117,7 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
     }
     const unsigned long long* list = rp.heavy_list;
     wg_bucket_sort_desc(count, [list](unsigned int i) { return (unsigned int)(list[i] >> 32); },
-                        [list](unsigned int i) { return (unsigned int)(list[i] & 0xFFFFFFFFull); }, rp.heavy_pixels, hist, &scratch);
+                        [list](unsigned int i) { return (unsigned int)(list[i] & 0xFFFFFFFFull); }, rp.heavy_pixels, hist, &scratch, &sort_hi, &sort_span);
     if (threadIdx.x == 0) { n_tier0 = 0u; n_tier1 = 0u; n_tier2 = 0u; }
     __syncthreads();
     unsigned int c0 = 0u, c1 = 0u, c2 = 0u;
@@ -127,6 +132,28 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
     if (c2) atomicAdd(&n_tier2, c2);
     __syncthreads();
     if (threadIdx.x != 0) return;
+    // The tiers trade throughput for latency (a sparse wave has an eighth of its lanes live), which only pays while they
+    // hold a small part of the frame's WORK: the dearest pixels are admitted while their rays so far stay within
+    // sparse_work_percent of all rays (bucket by bucket, from the sort's histogram); everything after them is tier 3.  In
+    // the Book-2 final scene 6 % of the pixels cost four times the mean and a quarter of the rays; in the random scene
+    // 0.1 % and 0.5 %.
+    {
+        const double budget = (double)*rp.ray_counter * (double)rp.sparse_work_percent / 100.0;
+        double work = 0.0;
+        unsigned int admitted = 0u, prev = 0u;
+        for (unsigned int b = 0; b < RANK_BUCKETS; ++b) {
+            const unsigned int upto = hist[b], nb = upto - prev;
+            prev = upto;
+            if (nb == 0u) continue;
+            const double cost_b = (double)sort_hi - ((double)b + 0.5) * (double)sort_span / (double)RANK_BUCKETS;
+            work += (double)nb * (cost_b > 0.0 ? cost_b : 0.0);
+            if (work > budget) break;
+            admitted = upto;
+        }
+        if (n_tier0 > admitted) n_tier0 = admitted;
+        if (n_tier1 > admitted) n_tier1 = admitted;
+        if (n_tier2 > admitted) n_tier2 = admitted;
+    }
     // ---- workgroups per tier.  tier 0 = one pixel per workgroup at a time, tier 1 = one per wave, tier 2 = 64 /
     // sparse_stride live lanes per wave; each queue is served dearest first and whatever exceeds its workgroups waits.
     const unsigned int cap_wgs = rp.max_grid * (unsigned int)rp.sparse_percent / 100u;
@@ -148,7 +175,7 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
     const unsigned int per_wg2 = rp.waves_per_wg * (64u / (unsigned int)rp.sparse_stride);
     unsigned int tier2_wgs = (tier2_items + per_wg2 - 1u) / per_wg2;
     if (tier0_wgs + tier1_wgs + tier2_wgs > cap_wgs) tier2_wgs = cap_wgs > tier0_wgs + tier1_wgs ? cap_wgs - tier0_wgs - tier1_wgs : 0u;
-    if (tier2_wgs == 0u) tier2_items = 0u;   // nobody to serve them sparsely: they join tier 3
+    if (tier2_items > tier2_wgs * per_wg2) tier2_items = tier2_wgs * per_wg2;   // what the sparse workgroups cannot hold at once joins tier 3
     const unsigned int sparse_wgs = tier0_wgs + tier1_wgs + tier2_wgs;
     // tier 3 on workgroups of their own with every semi_stride-th lane live (a lane's rays advance faster the fewer lanes
     // its wave has), as many as hold the whole tier at once
