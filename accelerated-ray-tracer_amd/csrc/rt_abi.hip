@@ -52,7 +52,8 @@ struct rt_options {
     int resplit_samples = 0;     // a second ranking: samples [split, resplit) run with tiers ranked on `split` samples, the rest ranked on `resplit` (0 = off)
     int presplit_samples = 8;    // a first, shorter look: samples [presplit, split) already run with tiers ranked on it (0 = off)
     int tier1_factor_x10 = 70;   // tier 1 = heavy pixels costing >= this/10 x the mean
-    int tier1_pixels = 256;      // heavy pixels served with one live lane per wave
+    int tier1_pixels = 256;      // heavy pixels served one per wave at a time (tier 1)
+    int tier1_depth = 1;         // ... each wave taking about this many of them, one after the other
     int heavy_factor_x10 = 20;   // a pixel is listed ("heavy") when its cost so far is >= this/10 x the mean ...
     int sparse_factor_x10 = 40;  // ... and goes to a sparse wave (tier 2) from this/10 x the mean; below, ordinary lanes take it first (tier 3)
     int heavy_max_tiles = 0;     // 0 = as many as the sparse workgroups hold at once
@@ -430,7 +431,8 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "resplit_samples") { if (value < 0 || value > 65536) return invalid("resplit_samples: 0..65536"); g_opt.resplit_samples = value; }
     else if (k == "split_samples") { if (value < 1 || value > 4096) return invalid("split_samples: 1..4096"); g_opt.split_samples = value; }
     else if (k == "tier1_factor_x10") { if (value < 10 || value > 10000) return invalid("tier1_factor_x10: 10..10000"); g_opt.tier1_factor_x10 = value; }
-    else if (k == "tier1_pixels") { if (value < 0 || value > 8192) return invalid("tier1_pixels: 0..8192"); g_opt.tier1_pixels = value; }
+    else if (k == "tier1_depth") { if (value < 1 || value > 64) return invalid("tier1_depth: 1..64"); g_opt.tier1_depth = value; }
+    else if (k == "tier1_pixels") { if (value < 0 || value > 65536) return invalid("tier1_pixels: 0..65536"); g_opt.tier1_pixels = value; }
     else if (k == "semi_stride") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return invalid("semi_stride: 0, 1, 2, 4 or 8"); g_opt.semi_stride = value; }
     else if (k == "sparse_eager") { if (value < 0 || value > 1) return invalid("sparse_eager: 0 or 1"); g_opt.sparse_eager = value; }
     else if (k == "sparse_priority") { if (value < 0 || value > 3) return invalid("sparse_priority: 0..3"); g_opt.sparse_priority = value; }
@@ -877,7 +879,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     // data -- header (16 B), 2 x 16 reduction slots (256 B), the leaf list (4 B per node: at most that many leaves)
     fp.tier0_lds_offset = 0;
     bool tier0_possible = false;
-    if (kernel == RT_KERNEL_STAGED && s->spheres_only && lds_mode == 2 && (g_opt.tier0_auto || g_opt.tier0_pixels > 0) && block.x >= 64 && block.x <= 1024) {
+    if (kernel == RT_KERNEL_STAGED && s->spheres_only && lds_mode == 2 && block.x >= 64 && block.x <= 1024) {
         const size_t scratch = ((size_t)16 + 256 + (size_t)s->dev.n_nodes * 4 + 255) & ~(size_t)255;
         if (lds_bytes + scratch + 512 <= g_lds_per_cu / (size_t)per_cu_resident) {
             fp.tier0_lds_offset = (uint32_t)lds_bytes;
@@ -955,7 +957,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             rp.sparse_percent = e_sparse_percent;
             rp.sparse_work_percent = g_opt.sparse_work_percent;
             rp.tier0_possible = tier0_possible ? 1 : 0;
-            rp.tier0_pixels = e_tier0_pixels; rp.tier1_pixels = e_tier1_pixels;
+            rp.tier0_pixels = e_tier0_pixels; rp.tier1_pixels = e_tier1_pixels; rp.tier1_depth = g_opt.tier1_depth;
             if (e_sparse_factor < e_heavy_factor) e_sparse_factor = e_heavy_factor;
             rp.heavy_factor = (float)e_heavy_factor / 10.0f; rp.sparse_factor = (float)e_sparse_factor / 10.0f; rp.tier1_factor = (float)g_opt.tier1_factor_x10 / 10.0f; rp.tier0_factor = (float)e_tier0_factor / 10.0f;
             HIPCHK(rt_launch_rank(rp, stream));

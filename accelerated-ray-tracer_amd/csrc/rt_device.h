@@ -70,6 +70,7 @@ struct rt_rank_params {
     int32_t sparse_work_percent;         // ... and tiers 0-2 together hold at most this share of the frame's rays so far
     int32_t tier0_possible;              // tier 0 needs a spheres-only scene resident in LDS
     int32_t tier0_pixels, tier1_pixels;  // caps on the tier sizes
+    int32_t tier1_depth;                 // pixels a tier-1 wave is meant to take, one after the other
     float heavy_factor, sparse_factor, tier1_factor, tier0_factor;   // cost thresholds as multiples of the mean cost per pixel:
                                          // >= heavy: in the list at all; >= sparse: tier 2; >= tier1 / tier0: those tiers
 };

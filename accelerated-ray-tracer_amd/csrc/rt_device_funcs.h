@@ -745,6 +745,84 @@ DEV bool trace_group(const SceneView& sc, const Ray& r, HitInfo& best, const uns
 }
 
 
+// One ray, one wave ("tier 1", spheres-only scenes with at most 64 * RT_WAVE_SLOTS leaves): every leaf's box lives in
+// the registers of one lane (slot k of lane l holds leaf 64 * k + l of the depth-first leaf list), so a ray is
+// RT_WAVE_SLOTS register-resident slab tests per lane, a sphere test (one LDS read) for the few leaves whose box passes,
+// and a minimum over the wave -- no dependent chain of LDS round trips at all.  A sequential walk costs ~390 cycles per
+// node under load (one LDS round trip + the slab arithmetic), ~11,700 per ray of the headline scene; this is ~2,500.
+// Same argument and same safeguards as trace_group(): the closest hit is the minimum of (t, leaf ordinal) over all
+// leaves whose own box passes without a limit; a candidate at or before its own box's entry distance (rounding on a
+// grazing ray) or a zero direction component hands the ray to the reference's walk.  The leaf list is in depth-first
+// order, so the leaf ordinal orders ties exactly as the node index does.
+#define RT_WAVE_SLOTS 8
+struct WaveLeaves {
+    float lo[RT_WAVE_SLOTS][3], hi[RT_WAVE_SLOTS][3];
+    int32_t prim[RT_WAVE_SLOTS];      // the leaf's sphere (< 0: no leaf in this slot)
+};
+DEV void wave_leaves_load(const SceneView& sc, const unsigned int* leaves, int n_leaves, WaveLeaves& w) {
+    const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+    for (int k = 0; k < RT_WAVE_SLOTS; ++k) {
+        const int q = k * 64 + lane;
+        w.prim[k] = -1;
+        w.lo[k][0] = w.lo[k][1] = w.lo[k][2] = 0.f; w.hi[k][0] = w.hi[k][1] = w.hi[k][2] = 0.f;
+        if (q < n_leaves) {
+            const rt_node nd = sc.nodes[leaves[q]];
+            w.lo[k][0] = nd.bmin[0]; w.lo[k][1] = nd.bmin[1]; w.lo[k][2] = nd.bmin[2];
+            w.hi[k][0] = nd.bmax[0]; w.hi[k][1] = nd.bmax[1]; w.hi[k][2] = nd.bmax[2];
+            w.prim[k] = nd.prim;
+        }
+    }
+}
+DEV bool trace_wave(const SceneView& sc, const Ray& r, HitInfo& best, const WaveLeaves& w, int n_leaves) {
+    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const float tmin = 0.001f;
+    if (!inv_is_finite(inv)) return trace<true>(sc, r, best);   // wave-uniform
+    const float a = dot(r.d, r.d);
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned long long key = ~0ull;
+    bool anomaly = false;
+#pragma unroll
+    for (int k = 0; k < RT_WAVE_SLOTS; ++k) {
+        if (k * 64 >= n_leaves) break;                           // wave-uniform
+        const float4 lo4 = make_float4(w.lo[k][0], w.lo[k][1], w.lo[k][2], 0.f), hi4 = make_float4(w.hi[k][0], w.hi[k][1], w.hi[k][2], 0.f);
+        float t_enter, t_exit;
+        slab_interval(lo4, hi4, r.o, inv, tmin, t_enter, t_exit);
+        const bool pass = w.prim[k] >= 0 && !(t_exit <= t_enter);
+        if (__ballot(pass) != 0ull) {
+            if (pass) {
+                float t;
+                if (sphere_test_a(sc.spheres[RT_PRIM_INDEX(w.prim[k])], r, a, tmin, FLT_MAX, t)) {
+                    if (!(t > t_enter)) anomaly = true;
+                    const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)(k * 64 + lane);
+                    if (kk < key) key = kk;
+                }
+            }
+        }
+    }
+    if (__ballot(anomaly) != 0ull) return trace<true>(sc, r, best);   // a grazing hit at or before its box's entry: the reference's walk decides
+    unsigned long long have = __ballot(key != ~0ull);
+    unsigned long long wkey = ~0ull;
+    const int klo = (int)(unsigned int)key, khi = (int)(unsigned int)(key >> 32);
+    int wprim = -1;
+    while (have != 0ull) {
+        const int l = __ffsll((long long)have) - 1;
+        have &= have - 1ull;
+        const unsigned long long kk = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(khi, l) << 32) |
+                                      (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(klo, l);
+        if (kk < wkey) wkey = kk;
+    }
+    best.inst = -1;
+    if (wkey == ~0ull) { best.t = FLT_MAX; best.prim = -1; return false; }
+    best.t = __uint_as_float((unsigned int)(wkey >> 32));
+    // the winner's sphere: slot and lane from its leaf ordinal
+    const int q = (int)(unsigned int)wkey, wslot = q >> 6, wlane = q & 63;
+#pragma unroll
+    for (int k = 0; k < RT_WAVE_SLOTS; ++k) if (k == wslot) wprim = __builtin_amdgcn_readlane(w.prim[k], wlane);
+    best.prim = wprim;
+    return true;
+}
+
 // aabb::hit for rays whose 1/d components are all finite: identical result to slab_test()
 DEV bool slab_test_finite(const float4 lo_skip, const float4 hi_prim, const f3 o, const f3 inv, float tmin, float tmax) {
     const float x0 = (lo_skip.x - o.x) * inv.x, x1 = (hi_prim.x - o.x) * inv.x;

@@ -101,16 +101,28 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
         unsigned long long* t0_slots = reinterpret_cast<unsigned long long*>(t0_scratch + 4);   // [2][16]
         unsigned int* t0_leaves = t0_scratch + 4 + 64;
         int t0_n_leaves = 0, t0_parity = 0;
-        if (tier0) {
-            if (threadIdx.x == 0) t0_scratch[0] = 0u;
-            __syncthreads();
-            for (int k = (int)threadIdx.x; k < n_nodes; k += (int)blockDim.x)
-                if (sc.nodes[k].prim >= 0) t0_leaves[atomicAdd(&t0_scratch[0], 1u)] = (unsigned int)k;
+        // the leaf list (node indices in depth-first order) behind the scene data: tier 0 deals it out one leaf per
+        // thread, tier 1 (spheres-only scenes resident in LDS) one leaf per lane and register slot (trace_wave)
+        const bool wave_leaves_ok = SPHERES_ONLY && LDS_MODE == 2 && fp.tier0_lds_offset != 0u;
+        if (tier0 || wave_leaves_ok) {
+            if (threadIdx.x < 64) {   // one wave: ballots give every leaf its place in order
+                int base = 0;
+                for (int k0 = 0; k0 < n_nodes; k0 += 64) {
+                    const int k = k0 + (int)threadIdx.x;
+                    const bool leaf = k < n_nodes && sc.nodes[k].prim >= 0;
+                    const unsigned long long m = __ballot(leaf);
+                    if (leaf) t0_leaves[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = (unsigned int)k;
+                    base += __popcll(m);
+                }
+                if (threadIdx.x == 0) t0_scratch[0] = (unsigned int)base;
+            }
             __syncthreads();
             t0_n_leaves = (int)t0_scratch[0];
         }
+        const bool tier1_wave = tier1 && wave_leaves_ok && t0_n_leaves <= 64 * RT_WAVE_SLOTS;   // workgroup-uniform
         // every lane of the wave (tier 1) / thread of the workgroup (tier 0) carries the same pixel and computes the same
         // values; only the traversal is shared out
+        auto tier_pixels = [&](auto trace_ray) {
         for (;;) {
             uint32_t idx = 0;
             if (tier0) {
@@ -144,7 +156,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
 #ifdef RT_DIAG
                     const unsigned long long dg0 = __builtin_readcyclecounter();
 #endif
-                    const bool hit = tier0 ? trace_group(sc, r, h, t0_leaves, t0_n_leaves, t0_slots, t0_parity) : trace_wide<SPHERES_ONLY>(sc, r, h);
+                    const bool hit = trace_ray(r, h);
 #ifdef RT_DIAG
                     const unsigned long long dg1 = __builtin_readcyclecounter();
                     if (threadIdx.x == 0) { diag_local[15] += 1; diag_local[14] += dg1 - dg0; }   // slots 14/15: tier loops only
@@ -175,6 +187,15 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                 rays += pixel_rays;
             }
         }
+        };
+        // three copies of the loop, one per traversal routine, so that the register image of trace_wave()'s leaf boxes is
+        // live only where it is used
+        if (SPHERES_ONLY && tier0) tier_pixels([&](const Ray& r, HitInfo& h) { return trace_group(sc, r, h, t0_leaves, t0_n_leaves, t0_slots, t0_parity); });
+        else if (SPHERES_ONLY && tier1_wave) {
+            WaveLeaves wl;
+            wave_leaves_load(sc, t0_leaves, t0_n_leaves, wl);
+            tier_pixels([&](const Ray& r, HitInfo& h) { return trace_wave(sc, r, h, wl, t0_n_leaves); });
+        } else tier_pixels([&](const Ray& r, HitInfo& h) { return trace_wide<SPHERES_ONLY>(sc, r, h); });
         __builtin_amdgcn_s_setprio(0);
         sparse = false;   // queue drained: this wave / workgroup becomes ordinary
     }

@@ -163,12 +163,12 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
     const unsigned int tier0_wgs = tier0_items;
     tier1_items = tier1_items > tier0_items ? tier1_items - tier0_items : 0u;            // tier 1 follows tier 0 in the list
     if (tier1_items > (unsigned int)rp.tier1_pixels) tier1_items = (unsigned int)rp.tier1_pixels;
-    unsigned int tier1_wgs = (tier1_items + rp.waves_per_wg - 1u) / rp.waves_per_wg;
-    if (tier0_wgs + tier1_wgs > cap_wgs / 2u + tier0_wgs / 2u) {
-        tier1_wgs = cap_wgs / 2u > tier0_wgs / 2u ? cap_wgs / 2u - tier0_wgs / 2u : 0u;
-        tier1_items = tier1_wgs * rp.waves_per_wg;
-        if (tier0_items + tier1_items > count) tier1_items = count - tier0_items;
-    }
+    // a tier-1 wave takes its pixels one after the other from the tier's queue (dearest first): tier1_depth of them on
+    // average, fewer workgroups than that only if the sparse share of the grid is used up
+    const unsigned int depth1 = rp.tier1_depth > 0 ? (unsigned int)rp.tier1_depth : 1u;
+    unsigned int tier1_wgs = (tier1_items + rp.waves_per_wg * depth1 - 1u) / (rp.waves_per_wg * depth1);
+    if (tier0_wgs + tier1_wgs > cap_wgs / 2u + tier0_wgs / 2u) tier1_wgs = cap_wgs / 2u > tier0_wgs / 2u ? cap_wgs / 2u - tier0_wgs / 2u : 0u;
+    if (tier1_wgs == 0u) tier1_items = 0u;
     // tier 2 = what is left of the pixels at or above the sparse threshold; tier 3 = the rest of the list
     unsigned int tier2_items = n_tier2 > tier0_items + tier1_items ? n_tier2 - tier0_items - tier1_items : 0u;
     if (tier0_items + tier1_items + tier2_items > count) tier2_items = count - tier0_items - tier1_items;

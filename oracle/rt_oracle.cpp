@@ -92,7 +92,14 @@ inline float axis_of(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); 
 
 // correctly rounded binary32 transcendentals (see header)
 inline float cr_powf(float x, float y) { return (float)pow((double)x, (double)y); }
-inline float cr_logf(float x) { return (float)log((double)x); }
+// Diagnostics (tools/medium_ulp_experiment.py, never a parity test): ORC_LOG_ULP=N moves the result by one ulp for the inputs
+// whose bit pattern is a multiple of N -- a stand-in for a logf that is not correctly rounded in a fraction of its inputs.
+static const int g_log_ulp_every = [] { const char* e = getenv("ORC_LOG_ULP"); return e ? atoi(e) : 0; }();
+inline float cr_logf(float x) {
+    const float v = (float)log((double)x);
+    if (g_log_ulp_every > 0) { uint32_t b; memcpy(&b, &x, 4); if (b % (uint32_t)g_log_ulp_every == 0u) return nextafterf(v, INFINITY); }
+    return v;
+}
 inline float cr_sinf(float x) { return (float)sin((double)x); }
 inline float cr_acosf(float x) { return (float)acos((double)x); }
 inline float cr_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }

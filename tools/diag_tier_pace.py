@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Cycles per ray in the tier loops of the staged kernel (diagnostic build: RT_LIB_OVERRIDE=.../librt_mi355x_diag.so).
+Thread 0 of every tier workgroup times its traversal calls (trace_group / trace_wave / trace_wide) with s_memtime.
+Usage: diag_tier_pace.py [key=value ...]        e.g. tier0_auto=0 tier0_pixels=64 tier0_factor_x10=80"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import accelerated_ray_tracer_amd as art
+art.init(0)
+for kv in sys.argv[1:]:
+    k, v = kv.split("="); art.set_option(k, int(v))
+hs = art.HostScene("random_scene", 1200, 800); ds = art.DeviceScene(hs)
+fb, st = ds.render(hs.frame(ns=500))
+c = np.zeros(16, np.uint64); L = art.rt_lib(); L.rt_debug_counters.argtypes = [C.c_void_p, C.c_void_p]; L.rt_debug_counters(ds._p, c.ctypes.data)
+c = [int(x) for x in c]
+print(sys.argv[1:], "frame %.1f ms (diag build)" % st.ms_render, "tier rays timed", c[15], "traversal cycles per ray %.0f" % (c[14] / max(c[15], 1)))

@@ -15,8 +15,10 @@ for k, v in opts.items(): art.set_option(k, int(v))
 img, iw, ih = art.default_texture(scene)
 hs = art.HostScene(scene, nx, ny, img, iw, ih)
 ds = art.DeviceScene(hs)
-fb, st = ds.render(hs.frame(nx=nx, ny=ny, ns=ns))
-fb, st = ds.render(hs.frame(nx=nx, ny=ny, ns=ns))
+stride, first = int(os.environ.get("STRIDE", "1")), int(os.environ.get("FIRST", "0"))   # one rank's share of a STRIDE-GPU run
+fkw = dict(nx=nx, ny=ny, ns=ns, tile_rows=4 if stride > 1 else ny, tile_first=first, tile_stride=stride)
+fb, st = ds.render(hs.frame(**fkw))
+fb, st = ds.render(hs.frame(**fkw))
 BINS = 192
 h = np.zeros(2 * BINS, np.uint64)
 L = art.rt_lib(); L.rt_debug_wave_ends.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
