@@ -53,6 +53,7 @@ struct rt_options {
     int presplit_samples = 8;    // a first, shorter look: samples [presplit, split) already run with tiers ranked on it (0 = off)
     int tier1_factor_x10 = 70;   // tier 1 = heavy pixels costing >= this/10 x the mean
     int tier1_pixels = 256;      // heavy pixels served one per wave at a time (tier 1)
+    int cost_smooth_percent = 0;  // ranking: a pixel's cost estimate is at least this share of its dearest 4-neighbour's (0 = own cost only)
     int tier1_depth = 1;         // ... each wave taking about this many of them, one after the other
     int heavy_factor_x10 = 20;   // a pixel is listed ("heavy") when its cost so far is >= this/10 x the mean ...
     int sparse_factor_x10 = 40;  // ... and goes to a sparse wave (tier 2) from this/10 x the mean; below, ordinary lanes take it first (tier 3)
@@ -431,6 +432,7 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "resplit_samples") { if (value < 0 || value > 65536) return invalid("resplit_samples: 0..65536"); g_opt.resplit_samples = value; }
     else if (k == "split_samples") { if (value < 1 || value > 4096) return invalid("split_samples: 1..4096"); g_opt.split_samples = value; }
     else if (k == "tier1_factor_x10") { if (value < 10 || value > 10000) return invalid("tier1_factor_x10: 10..10000"); g_opt.tier1_factor_x10 = value; }
+    else if (k == "cost_smooth_percent") { if (value < 0 || value > 100) return invalid("cost_smooth_percent: 0..100"); g_opt.cost_smooth_percent = value; }
     else if (k == "tier1_depth") { if (value < 1 || value > 64) return invalid("tier1_depth: 1..64"); g_opt.tier1_depth = value; }
     else if (k == "tier1_pixels") { if (value < 0 || value > 65536) return invalid("tier1_pixels: 0..65536"); g_opt.tier1_pixels = value; }
     else if (k == "semi_stride") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return invalid("semi_stride: 0, 1, 2, 4 or 8"); g_opt.semi_stride = value; }
@@ -958,6 +960,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             rp.sparse_work_percent = g_opt.sparse_work_percent;
             rp.tier0_possible = tier0_possible ? 1 : 0;
             rp.tier0_pixels = e_tier0_pixels; rp.tier1_pixels = e_tier1_pixels; rp.tier1_depth = g_opt.tier1_depth;
+            rp.nx = f->nx; rp.smooth_percent = g_opt.cost_smooth_percent;
             if (e_sparse_factor < e_heavy_factor) e_sparse_factor = e_heavy_factor;
             rp.heavy_factor = (float)e_heavy_factor / 10.0f; rp.sparse_factor = (float)e_sparse_factor / 10.0f; rp.tier1_factor = (float)g_opt.tier1_factor_x10 / 10.0f; rp.tier0_factor = (float)e_tier0_factor / 10.0f;
             HIPCHK(rt_launch_rank(rp, stream));

@@ -30,7 +30,7 @@ enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_STAGED = 3, RT_KERNEL_WAVEFRONT = 4 };
 struct rt_pixel_state {
     uint32_t rng[6];
     float col[3];
-    uint32_t cost;
+    uint32_t cost;               // rays so far; bit 31 = "on the heavy list of the coming launch" (set by the ranking)
 };
 
 // What the ranking kernels (rt_rank.hip) leave for the next render launch of a split frame: how many parked pixels are
@@ -55,7 +55,7 @@ struct rt_rank_info {
 
 // constants of one ranking (host-filled kernel argument)
 struct rt_rank_params {
-    const rt_pixel_state* state;
+    rt_pixel_state* state;               // (the ranking marks listed pixels in bit 31 of their cost)
     const unsigned int* tile_cost;
     unsigned int* tile_order;
     const unsigned long long* ray_counter;
@@ -71,6 +71,7 @@ struct rt_rank_params {
     int32_t tier0_possible;              // tier 0 needs a spheres-only scene resident in LDS
     int32_t tier0_pixels, tier1_pixels;  // caps on the tier sizes
     int32_t tier1_depth;                 // pixels a tier-1 wave is meant to take, one after the other
+    int32_t nx, smooth_percent;          // cost estimate of a pixel = max(own, smooth_percent % of its dearest 4-neighbour's); nx = pixels per local row
     float heavy_factor, sparse_factor, tier1_factor, tier0_factor;   // cost thresholds as multiples of the mean cost per pixel:
                                          // >= heavy: in the list at all; >= sparse: tier 2; >= tier1 / tier0: those tiers
 };

@@ -178,7 +178,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                 if (fp.state_out) {   // a middle part of a split frame: park the pixel again
                     rt_pixel_state so;
                     so.rng[0] = pg.v0; so.rng[1] = pg.v1; so.rng[2] = pg.v2; so.rng[3] = pg.v3; so.rng[4] = pg.v4; so.rng[5] = pg.d;
-                    so.col[0] = pcol.x; so.col[1] = pcol.y; so.col[2] = pcol.z; so.cost = fp.state_in[pix].cost + pixel_rays;
+                    so.col[0] = pcol.x; so.col[1] = pcol.y; so.col[2] = pcol.z; so.cost = fp.state_in[pix].cost + pixel_rays;   // (bit 31, "listed", stays: this launch's tile queue must keep skipping the pixel)
                     fp.state_out[pix] = so;
                     atomicAdd(&fp.tile_cost[(lrow >> 3) * fp.tiles_x + (i >> 3)], pixel_rays);
                 } else {
@@ -453,7 +453,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                             rt_pixel_state st;
                             st.rng[0] = g.v0; st.rng[1] = g.v1; st.rng[2] = g.v2; st.rng[3] = g.v3; st.rng[4] = g.v4; st.rng[5] = g.d;
                             st.col[0] = col.x; st.col[1] = col.y; st.col[2] = col.z;
-                            st.cost = c + (fp.state_in ? fp.state_in[at].cost : 0u);   // a middle part adds to what the pixel cost before
+                            st.cost = c + (fp.state_in ? fp.state_in[at].cost : 0u);   // a middle part adds to what the pixel cost before (bit 31, "listed", stays)   // a middle part adds to what the pixel cost before
                             fp.state_out[at] = st;
                             atomicAdd(&fp.tile_cost[(px_lrow >> 3) * fp.tiles_x + (px_i >> 3)], c);
                         } else {
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                             if (w >= fp.work_items) { alive = false; break; }
                             ok = work_to_pixel(fp, w, px_i, px_lrow);
                             // pixels in the heavy list belong to the tiers
-                            if (ok && rk.heavy_items && fp.state_in[(size_t)px_lrow * fp.nx + px_i].cost >= rk.heavy_threshold) ok = false;
+                            if (ok && rk.heavy_items && (fp.state_in[(size_t)px_lrow * fp.nx + px_i].cost & 0x80000000u) != 0u) ok = false;
                         }
                         if (ok) {
 #ifdef RT_DIAG

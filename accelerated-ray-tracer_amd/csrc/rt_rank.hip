@@ -90,12 +90,28 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_tiles_kernel(rt_rank_par
     wg_bucket_sort_desc(rp.n_tiles, [cost](unsigned int i) { return cost[i]; }, [](unsigned int i) { return i; }, rp.tile_order, hist, &scratch);
 }
 
-// every pixel whose parked cost reaches the heavy threshold is appended as (cost << 32 | pixel)
+// every pixel whose cost estimate reaches the heavy threshold is appended as (estimate << 32 | pixel).  The estimate is the
+// pixel's own rays so far, or -- a pixel's cost over 32 samples is a noisy predictor of its cost over 500 when its paths
+// go through glass -- smooth_percent of its dearest 4-neighbour's, whichever is larger.
 __global__ void rt_collect_heavy_kernel(rt_rank_params rp) {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rp.n_pixels) return;
     const unsigned int threshold = rp.info->heavy_threshold;
-    const unsigned int c = rp.state[i].cost;
+    const unsigned int own = rp.state[i].cost & 0x7FFFFFFFu;
+    unsigned int c = own;
+    if (rp.smooth_percent > 0 && rp.nx > 0) {
+        const unsigned int x = i % (unsigned int)rp.nx;
+        unsigned int m = 0u;
+        if (x > 0u) m = rp.state[i - 1].cost & 0x7FFFFFFFu;
+        if (x + 1u < (unsigned int)rp.nx && i + 1u < rp.n_pixels) { const unsigned int v = rp.state[i + 1].cost & 0x7FFFFFFFu; m = v > m ? v : m; }
+        if (i >= (unsigned int)rp.nx) { const unsigned int v = rp.state[i - rp.nx].cost & 0x7FFFFFFFu; m = v > m ? v : m; }
+        if (i + (unsigned int)rp.nx < rp.n_pixels) { const unsigned int v = rp.state[i + rp.nx].cost & 0x7FFFFFFFu; m = v > m ? v : m; }
+        m &= 0x7FFFFFFFu;   // (a neighbour may already carry this ranking's list flag)
+        const unsigned int sm = (unsigned int)(((unsigned long long)m * (unsigned int)rp.smooth_percent) / 100ull);
+        c = sm > c ? sm : c;
+    }
+    // bit 31 of the parked cost says "listed": the render kernel's tile queue skips exactly these pixels
+    rp.state[i].cost = own | (c >= threshold ? 0x80000000u : 0u);
     if (c >= threshold) {
         const unsigned int at = atomicAdd(&rp.info->collected, 1u);
         if (at < rp.heavy_cap) rp.heavy_list[at] = ((unsigned long long)c << 32) | i;

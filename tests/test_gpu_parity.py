@@ -184,7 +184,9 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
                 # tier 3 (listed pixels below the sparse threshold): on ordinary lanes, on semi workgroups, none; a second ranking
                 (3, {"split_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 30, "semi_stride": 0}), (3, {"split_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 30, "semi_stride": 2}),
                 (3, {"split_samples": 2, "presplit_samples": 1, "heavy_factor_x10": 12, "sparse_factor_x10": 20, "semi_stride": 4, "tier1_pixels": 0}),
-                (3, {"split_samples": 1, "resplit_samples": 3, "heavy_factor_x10": 10, "sparse_factor_x10": 15}), (3, {"split_samples": 2, "resplit_samples": 3, "presplit_samples": 1, "semi_stride": 8, "heavy_factor_x10": 10})]
+                (3, {"split_samples": 1, "resplit_samples": 3, "heavy_factor_x10": 10, "sparse_factor_x10": 15}),
+                (3, {"split_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 20, "cost_smooth_percent": 90, "tier1_pixels": 64, "tier1_factor_x10": 20, "tier1_depth": 4}),
+                (3, {"split_samples": 2, "presplit_samples": 1, "heavy_factor_x10": 15, "cost_smooth_percent": 100, "sparse_work_percent": 1}), (3, {"split_samples": 3, "heavy_factor_x10": 10, "sparse_work_percent": 100}), (3, {"split_samples": 2, "resplit_samples": 3, "presplit_samples": 1, "semi_stride": 8, "heavy_factor_x10": 10})]
     for kernel, opts in variants:
         fb, st = render(gpu, hs, kernel, opts, ns=6)
         assert st.rays == st0.rays, (kernel, opts)
