@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 # ALGORITHMIC bytes per ray: node, sphere and material records the
 # reference's traversal touches per ray, counted on the reference's own tree for this scene
 # (40.15 box tests x 32 B + 3.99 sphere tests x 32 B + ~1.1 material reads x 16 B).
-ALGO_BYTES_PER_RAY = {"bouncing": 1430.0, "random_scene": 1430.0, "book1": 1430.0, "cornell": 980.0, "final": 2500.0}
+ALGO_BYTES_PER_RAY = {"bouncing": 1430.0, "random_scene": 1430.0, "book1": 1430.0, "cornell": 980.0, "cornell_smoke": 1340.0, "final": 2500.0}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # VALU issue: 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md "Wave scheduling",
 # cycle-constants row v_fma_f32: 2 cyc throughput), max clock 2.4 GHz  ->  1228.8 G wave-instructions / s.

@@ -18,7 +18,10 @@
 // full frames in profiles/r01_reference_image_match.txt): it reproduces the
 // pinned rows of quads, checker, earth, perlin, simple_light, Cornell and the
 // headline random scene (the last three at 10000 spp) pixel for pixel, and the
-// two scenes whose rays all pass a constant_medium to Monte-Carlo noise.
+// two scenes whose rays all pass a constant_medium to Monte-Carlo noise only:
+// the constant_medium path (constant_medium.cuh:36-76) is PARITY UNPINNED
+// against the reference -- no output the reference holds can pin it
+// (profiles/r02_medium_log_ulp_experiment.txt).
 // That pins the XORWOW stream (restated here from the published cuRAND
 // algorithm), per-pixel seeding, draw order, scene construction, BVH rules,
 // hit routines, materials, textures, camera, accumulation, gamma and the

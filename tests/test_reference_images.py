@@ -97,7 +97,10 @@ GPU_CASES = {
     "simple_light": (0.999, 1.0, 0.002),
     "bouncing":     (0.9999, 1.0, 0.0005),    # 1.0 at 10000 spp, 1.9 G rays
     "cornell":      (0.9995, 1.0, 0.001),     # 1.0 at 10000 spp, 3.1 G rays
-    "original":     (0.07, 0.28, 2.6),        # noise level, see the box-mean test
+    # constant_medium scenes: PARITY UNPINNED against the reference.  Their rows agree with the
+    # reference image as an independent 10000-spp render does (profiles/r02_medium_log_ulp_experiment.txt); these bounds
+    # only catch a gross regression -- the distribution itself is checked by the box-mean test below.
+    "original":     (0.07, 0.28, 2.6),
     "final":        (0.06, 0.20, 3.5),
 }
 
@@ -123,12 +126,13 @@ def test_hip_path_reproduces_reference_image(gpu, scene):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene,ns,max_mae,min_corr", [("final", 2500, 1.5, 0.9995), ("original", 2500, 1.5, 0.9995)])
+@pytest.mark.parametrize("scene,ns,max_mae,min_corr", [("final", 2500, 1.0, 0.9997), ("original", 2500, 1.0, 0.9997)])
 def test_long_chain_scenes_agree_in_the_mean(gpu, scene, ns, max_mae, min_corr):
     """The two 10000-spp scenes with media / procedural textures diverge from the reference's sample streams in most
     pixels (see the module docstring), so their rows only agree to noise.  What must still hold is that the image is
     a sample of the same distribution: 8x8 box means of the whole frame (64 x ns samples each) against the
-    reference image's box means.  Measured at 10000 spp: MAE 0.47 / 0.39 of 255, correlation 0.9999."""
+    reference image's box means.  Measured at 10000 spp: MAE 0.47 / 0.39 of 255, correlation 0.9999; at the 2500 spp
+    rendered here 0.67 / 0.43 (profiles/r01g_gpu_tests.log), so the gate sits at 1.0 -- about 1.5 x the measured noise."""
     img, iw, ih = gpu.default_texture(scene)
     hs = gpu.HostScene(scene, 0, 0, img, iw, ih)
     ds = gpu.DeviceScene(hs)
