@@ -604,8 +604,36 @@ rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_sce
     } while (0)
     UP(nodes_ref, d->n_nodes);
     UP(spheres, d->n_spheres);
-    UP(quads, d->n_quads);
-    UP(boxes, d->n_boxes);
+    {   // quads and boxes: mark the axis-aligned ones (quad_test_axis, rt_device_funcs.h).  A quad qualifies when its unit
+        // normal is exactly +-e_C and u, v, w each have exactly one non-zero component on the fitting axes; a box when its
+        // six faces do, with normals along z, x, z, x, y, y (make_box's order, quad.cuh:145-162).
+        std::vector<rt_quad> quads(d->quads, d->quads + d->n_quads);
+        auto axis_of = [](const rt_quad& q) -> int {
+            for (int c = 0; c < 3; ++c) {
+                const int a = (c + 1) % 3, b = (c + 2) % 3;
+                if (!((q.n[c] == 1.0f || q.n[c] == -1.0f) && q.n[a] == 0.0f && q.n[b] == 0.0f)) continue;
+                if (!(q.w[a] == 0.0f && q.w[b] == 0.0f && q.w[c] != 0.0f && q.u[c] == 0.0f && q.v[c] == 0.0f)) continue;
+                const bool u_on_a = q.u[a] != 0.0f && q.u[b] == 0.0f, u_on_b = q.u[b] != 0.0f && q.u[a] == 0.0f;
+                const bool v_on_a = q.v[a] != 0.0f && q.v[b] == 0.0f, v_on_b = q.v[b] != 0.0f && q.v[a] == 0.0f;
+                if ((u_on_a && v_on_b) || (u_on_b && v_on_a)) return c;
+            }
+            return -1;
+        };
+        for (rt_quad& q : quads) { const int c = axis_of(q); const int32_t code = c >= 0 ? 1 + c : 0; memcpy(&q.pad0, &code, 4); }
+        std::vector<rt_box> boxes(d->boxes, d->boxes + d->n_boxes);
+        static const int face_axis[6] = {2, 0, 2, 0, 1, 1};
+        for (rt_box& b : boxes) {
+            bool canonical = true;
+            for (int f = 0; f < 6 && canonical; ++f) canonical = axis_of(quads[(size_t)b.first_quad + f]) == face_axis[f];
+            if (canonical) b.first_quad |= 0x40000000;
+        }
+        st = upload(quads.data(), quads.size(), &s->dev.quads);
+        if (st != RT_OK) { rt_scene_destroy(s); return st; }
+        s->allocs.push_back(const_cast<void*>(static_cast<const void*>(s->dev.quads)));
+        st = upload(boxes.data(), boxes.size(), &s->dev.boxes);
+        if (st != RT_OK) { rt_scene_destroy(s); return st; }
+        s->allocs.push_back(const_cast<void*>(static_cast<const void*>(s->dev.boxes)));
+    }
     UP(instances, d->n_instances);
     UP(media, d->n_media);
     {   // materials: `pad` tells resolve_hit() whether the material's texture reads the hit's (u, v)

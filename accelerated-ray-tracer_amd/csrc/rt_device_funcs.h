@@ -140,8 +140,46 @@ DEV bool quad_test(const rt_quad& q, const Ray& r, float tmin, float tmax, float
     return true;
 }
 
+// quad::hit for a quad whose unit normal is exactly +-e_C, whose u and v have one non-zero component each (on the other
+// two axes) and whose w = n / dot(n, n) therefore has one too: an axis-aligned rectangle -- every wall of the Cornell box,
+// every face of make_box (quad.cuh:145-162).  rt_scene_create verifies those exact zeros per quad and marks the quad
+// (rt_quad.pad0) / the box (bit 30 of first_quad).  With them, the general expressions above collapse without changing a
+// bit of what is compared: dot(n, x) = fma(n.z, x.z, fma(n.x, x.x, n.y * x.y)) is n_C * x_C plus exact zeros; dot(w, X) is
+// w_C * X_C; X_C = cross(.,.)_C reads only the two in-plane components of pl.  (The only thing that can differ is the sign
+// of a zero in denom, alpha or beta, which no comparison below sees: |denom| < 1e-8 misses either way, +-0 is neither < 0
+// nor > 1.)  ~35 instructions instead of ~60.
+template <int C> DEV float comp(const f3& v) { return C == 0 ? v.x : (C == 1 ? v.y : v.z); }
+template <int C>
+DEV bool quad_test_axis(const rt_quad& q, const Ray& r, float tmin, float tmax, float& t_out) {
+    constexpr int A = (C + 1) % 3, B = (C + 2) % 3;
+    const float s = q.n[C];
+    const float denom = s * comp<C>(r.d);
+    if (fabsf(denom) < 1e-8f) return false;
+    const float t = (q.D - s * comp<C>(r.o)) / denom;
+    if (t < tmin || t > tmax) return false;
+    const float plA = fmaf(t, comp<A>(r.d), comp<A>(r.o)) - q.Q[A];     // ray.point_at_parameter(t) - Q, in-plane components
+    const float plB = fmaf(t, comp<B>(r.d), comp<B>(r.o)) - q.Q[B];
+    // component C of cross(pl, v) and of cross(u, pl), by the general formula of cross() for that component
+    float xa, xb;
+    if (C == 1) {   // cross(a, b).y = -fma(a.x, b.z, -(a.z * b.x)); here A = z, B = x
+        xa = -fmaf(plB, q.v[A], -(plA * q.v[B]));
+        xb = -fmaf(q.u[B], plA, -(q.u[A] * plB));
+    } else {        // cross(a, b).x = fma(a.y, b.z, -(a.z * b.y)) (A = y, B = z); .z = fma(a.x, b.y, -(a.y * b.x)) (A = x, B = y)
+        xa = fmaf(plA, q.v[B], -(plB * q.v[A]));
+        xb = fmaf(q.u[A], plB, -(q.u[B] * plA));
+    }
+    const float alpha = q.w[C] * xa, beta = q.w[C] * xb;
+    if (alpha < 0.f || alpha > 1.f || beta < 0.f || beta > 1.f) return false;
+    t_out = t;
+    return true;
+}
+// the quad's marking: 0 = general quad, 1 + C = axis-aligned with normal axis C
+DEV int quad_axis_code(const rt_quad& q) { return __float_as_int(q.pad0); }
+
 // sphere | quad | compound6 (quad.cuh:124-139: closest-hit scan over six faces,
 // no box early-out).  On a hit, `leaf` is the resolved sphere/quad ref.
+// UNIFORM: `ref` is the same in every lane (scan mode, tier loops), so a quad's axis code is a scalar branch.
+template <bool UNIFORM = false>
 DEV bool simple_test(const SceneView& sc, int32_t ref, const Ray& r, float tmin, float tmax, float& t_out, int32_t& leaf) {
     const int kind = RT_PRIM_KIND(ref), idx = RT_PRIM_INDEX(ref);
     if (kind == RT_PRIM_SPHERE) {
@@ -150,16 +188,34 @@ DEV bool simple_test(const SceneView& sc, int32_t ref, const Ray& r, float tmin,
     }
     if (kind == RT_PRIM_QUAD) {
         leaf = ref;
+        if (UNIFORM) {
+            const int code = __builtin_amdgcn_readfirstlane(quad_axis_code(sc.quads[idx]));
+            if (code == 1) return quad_test_axis<0>(sc.quads[idx], r, tmin, tmax, t_out);
+            if (code == 2) return quad_test_axis<1>(sc.quads[idx], r, tmin, tmax, t_out);
+            if (code == 3) return quad_test_axis<2>(sc.quads[idx], r, tmin, tmax, t_out);
+        }
         return quad_test(sc.quads[idx], r, tmin, tmax, t_out);
     }
     // box
-    const int first = sc.boxes[idx].first_quad;
+    const int first_raw = sc.boxes[idx].first_quad, first = first_raw & 0x3FFFFFFF;
     bool any = false;
     float closest = tmax;
-    for (int f = 0; f < 6; ++f) {
+    if (first_raw & 0x40000000) {
+        // make_box's faces in its order (front, right, back, left, top, bottom): normals along z, x, z, x, y, y -- verified
+        // per box by rt_scene_create
         float t;
-        if (quad_test(sc.quads[first + f], r, tmin, closest, t)) {
-            any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + f);
+        if (quad_test_axis<2>(sc.quads[first + 0], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 0); }
+        if (quad_test_axis<0>(sc.quads[first + 1], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 1); }
+        if (quad_test_axis<2>(sc.quads[first + 2], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 2); }
+        if (quad_test_axis<0>(sc.quads[first + 3], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 3); }
+        if (quad_test_axis<1>(sc.quads[first + 4], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 4); }
+        if (quad_test_axis<1>(sc.quads[first + 5], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 5); }
+    } else {
+        for (int f = 0; f < 6; ++f) {
+            float t;
+            if (quad_test(sc.quads[first + f], r, tmin, closest, t)) {
+                any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + f);
+            }
         }
     }
     t_out = closest;
@@ -180,28 +236,30 @@ DEV Ray to_object_space(const rt_instance& in, const Ray& r) {
 }
 
 // any leaf object except a medium: simple or instance-of-simple
+template <bool UNIFORM = false>
 DEV bool solid_test(const SceneView& sc, int32_t ref, const Ray& r, float tmin, float tmax, float& t_out, int32_t& leaf, int32_t& inst) {
     if (RT_PRIM_KIND(ref) == RT_PRIM_INSTANCE) {
         inst = RT_PRIM_INDEX(ref);
         const rt_instance in = sc.instances[inst];
         const Ray q = to_object_space(in, r);
-        return simple_test(sc, in.child, q, tmin, tmax, t_out, leaf);
+        return simple_test<UNIFORM>(sc, in.child, q, tmin, tmax, t_out, leaf);
     }
     inst = -1;
-    return simple_test(sc, ref, r, tmin, tmax, t_out, leaf);
+    return simple_test<UNIFORM>(sc, ref, r, tmin, tmax, t_out, leaf);
 }
 
 // constant_medium::hit (constant_medium.cuh:36-64) behind the 4-argument
 // fallback (:67-76), which is the only form a BVH ever calls (bvh.cuh:109-112):
 // a private XORWOW seeded from a hash of the ray supplies the one uniform.
+template <bool UNIFORM = false>
 DEV bool medium_test(const SceneView& sc, const rt_medium& m, const Ray& r, float tmin, float tmax, float& t_out) {
     rt_xorwow fake;
     const uint32_t seed = 1337u ^ __float_as_uint(r.o.x) ^ __float_as_uint(r.o.y * 3.1f) ^ __float_as_uint(r.d.z * 5.7f);
     rt_xorwow_seed(fake, (uint64_t)seed);
     float t1, t2;
     int32_t leaf, inst;
-    if (!solid_test(sc, m.boundary, r, -FLT_MAX, FLT_MAX, t1, leaf, inst)) return false;
-    if (!solid_test(sc, m.boundary, r, t1 + 1e-4f, FLT_MAX, t2, leaf, inst)) return false;
+    if (!solid_test<UNIFORM>(sc, m.boundary, r, -FLT_MAX, FLT_MAX, t1, leaf, inst)) return false;
+    if (!solid_test<UNIFORM>(sc, m.boundary, r, t1 + 1e-4f, FLT_MAX, t2, leaf, inst)) return false;
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
@@ -220,7 +278,7 @@ DEV bool medium_test(const SceneView& sc, const rt_medium& m, const Ray& r, floa
 // in a single-object node, bvh.cuh:38-43,100-101); the second test runs with
 // tmax = the first hit's t and either misses or reproduces the same record
 // for every object kind, so one test gives the same result.
-template <bool SPHERES_ONLY>
+template <bool SPHERES_ONLY, bool UNIFORM = false>
 DEV void leaf_test(const SceneView& sc, int32_t ref, const Ray& r, float tmin, HitInfo& best) {
     float t;
     if (SPHERES_ONLY) {
@@ -229,10 +287,10 @@ DEV void leaf_test(const SceneView& sc, int32_t ref, const Ray& r, float tmin, H
     }
     int32_t leaf = ref, inst = -1;
     if (RT_PRIM_KIND(ref) == RT_PRIM_MEDIUM) {
-        if (medium_test(sc, sc.media[RT_PRIM_INDEX(ref)], r, tmin, best.t, t)) { best.t = t; best.prim = ref; best.inst = -1; }
+        if (medium_test<UNIFORM>(sc, sc.media[RT_PRIM_INDEX(ref)], r, tmin, best.t, t)) { best.t = t; best.prim = ref; best.inst = -1; }
         return;
     }
-    if (solid_test(sc, ref, r, tmin, best.t, t, leaf, inst)) { best.t = t; best.prim = leaf; best.inst = inst; }
+    if (solid_test<UNIFORM>(sc, ref, r, tmin, best.t, t, leaf, inst)) { best.t = t; best.prim = leaf; best.inst = inst; }
 }
 
 // aabb::hit (aabb.cuh:45-61) with 1/direction hoisted out of the node loop
@@ -655,7 +713,7 @@ DEV bool trace_wide(const SceneView& sc, const Ray& r, HitInfo& best) {
             if ((leaf_mask >> bit) & 1ull) {
                 const float before = best.t;
                 const int32_t before_prim = best.prim;
-                leaf_test<SPHERES_ONLY>(sc, __builtin_amdgcn_readlane(my_prim, bit), r, tmin, best);
+                leaf_test<SPHERES_ONLY, true>(sc, __builtin_amdgcn_readlane(my_prim, bit), r, tmin, best);
                 j = __builtin_amdgcn_readlane(my_skip, bit);
                 if (best.t != before || best.prim != before_prim) break;   // later boxes must see the new limit
             } else {

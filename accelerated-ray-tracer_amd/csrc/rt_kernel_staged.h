@@ -226,7 +226,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                         if (active && !pass) resume = skip;
                     } else if (__ballot(pass) != 0ull) {
                         DIAG_ADD(3, 1); DIAG_ADD(4, __popcll(__ballot(pass)));
-                        if (pass) leaf_test<SPHERES_ONLY>(sc, prim, cur, tmin, best);
+                        if (pass) leaf_test<SPHERES_ONLY, true>(sc, prim, cur, tmin, best);
                     }
                 }
                 if (scanning) node = ST_DONE;
