@@ -72,7 +72,7 @@ MATERIAL_DTYPE = np.dtype([("kind", "<i4"), ("tex", "<i4"), ("fuzz", "<f4"), ("i
 RT_ABI_SYMBOLS = ["rt_init", "rt_shutdown", "rt_strerror", "rt_last_hip_error", "rt_last_error_detail", "rt_scene_create",
                   "rt_scene_destroy", "rt_frame_local_rows", "rt_local_to_global_row", "rt_render", "rt_frame_finish",
                   "rt_set_option", "rt_reset_options", "rt_scene_walk_info", "rt_init_devices", "rt_multi_create", "rt_multi_render",
-                  "rt_multi_destroy", "rt_multi_device_count", "rt_multi_row_owner"]
+                  "rt_multi_destroy", "rt_multi_device_count", "rt_multi_row_owner", "rt_plan_walk_array"]
 
 _rt = None
 _host = None
@@ -135,6 +135,8 @@ def rt_lib():
         L.rt_multi_destroy.argtypes = [C.c_void_p]
         L.rt_multi_device_count.argtypes = [C.c_void_p]
         L.rt_multi_row_owner.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.rt_plan_walk_array.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rt_scene_walk_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _rt = L
     return _rt
@@ -333,6 +335,19 @@ class MultiScene:
             self.close()
         except Exception:
             pass
+
+
+def plan_walk_array(nodes: np.ndarray, passes=None, root_visits: float = 0.0):
+    """The walk array rt_scene_create would derive from `nodes` (NODE_DTYPE) for the given per-node pass counts (None = by
+    surface area).  Host only.  Returns (walk nodes, tests per ray before, after)."""
+    nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
+    n = len(nodes)
+    out = np.zeros(n, NODE_DTYPE)
+    n_out, tb, ta = C.c_int32(0), C.c_double(0), C.c_double(0)
+    p = None if passes is None else np.ascontiguousarray(passes, np.float64)
+    _check(rt_lib().rt_plan_walk_array(nodes.ctypes.data, n, None if p is None else p.ctypes.data, float(root_visits), out.ctypes.data, n,
+                                       C.byref(n_out), C.byref(tb), C.byref(ta)), "rt_plan_walk_array")
+    return out[: n_out.value].copy(), tb.value, ta.value
 
 
 def row_owner(global_row: int, tile_rows: int, n_gpus: int):

@@ -680,6 +680,33 @@ rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_sce
 
 extern "C" {
 
+// Host-only: the walk array rt_scene_create would build for `nodes` given per-node pass counts (`pass`, one per node;
+// null = proportional to box surface area) and `root_visits` rays.  Writes at most `cap` nodes to `out`, returns the
+// walk array's size through `n_out` and the expected box tests per ray before / after.  No device involved.
+rt_status rt_plan_walk_array(const rt_node* nodes, int32_t n, const double* pass, double root_visits, rt_node* out, int32_t cap,
+                             int32_t* n_out, double* tests_before, double* tests_after) {
+    if (!nodes || n <= 0 || !n_out) return invalid("rt_plan_walk_array: bad argument");
+    for (int i = 0; i < n; ++i) if (nodes[i].skip <= i || nodes[i].skip > n) return invalid("node skip link does not move forward");
+    std::vector<double> p((size_t)n, 0.0);
+    if (pass) p.assign(pass, pass + n);
+    else {
+        for (int i = 0; i < n; ++i) {
+            const double ex = fmax(0.0, (double)nodes[i].bmax[0] - nodes[i].bmin[0]), ey = fmax(0.0, (double)nodes[i].bmax[1] - nodes[i].bmin[1]),
+                         ez = fmax(0.0, (double)nodes[i].bmax[2] - nodes[i].bmin[2]);
+            p[i] = 2.0 * (ex * ey + ey * ez + ex * ez);
+        }
+        root_visits = p[0];
+    }
+    collapse_plan plan;
+    std::vector<rt_node> walk(nodes, nodes + n);
+    if (plan_collapse(nodes, n, p, root_visits, plan)) walk = build_walk_array(nodes, n, plan.keep);
+    *n_out = (int32_t)walk.size();
+    if (tests_before) *tests_before = plan.tests_before;
+    if (tests_after) *tests_after = plan.tests_after;
+    if (out) for (int i = 0; i < (int)walk.size() && i < cap; ++i) out[i] = walk[i];
+    return RT_OK;
+}
+
 rt_status rt_scene_walk_info(const rt_scene* s, int32_t* nodes_reference, int32_t* nodes_walked, double* tests_before, double* tests_after) {
     if (!s) return invalid("null scene");
     if (nodes_reference) *nodes_reference = s->dev.n_nodes_ref;

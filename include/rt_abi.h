@@ -201,6 +201,10 @@ rt_status rt_scene_destroy(rt_scene* scene);
  * node counts and the expected box tests per ray before / after on the calibration frame (0 when nothing was removed). */
 rt_status rt_scene_walk_info(const rt_scene* scene, int32_t* nodes_reference, int32_t* nodes_walked,
                              double* tests_before, double* tests_after);
+/* The planner behind it, host only (no device needed): the walk array for `nodes` given per-node counts of passing box
+ * tests (`pass`, null = proportional to box surface area) out of `root_visits` rays.  out/cap may be null/0. */
+rt_status rt_plan_walk_array(const rt_node* nodes, int32_t n, const double* pass, double root_visits, rt_node* out, int32_t cap,
+                             int32_t* n_out, double* tests_before, double* tests_after);
 
 /* Number of rows a frame description assigns to this call, and the mapping
  * from a compact local row to its global row. */

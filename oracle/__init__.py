@@ -91,6 +91,22 @@ class OracleScene:
         lib().orc_dump_nodes(self.h, out.ctypes.data, n)
         return out
 
+    def node_passes(self, ns: int, threads: int = 0) -> tuple:
+        """Diagnostics: renders the frame at `ns` spp counting, per BVH node (depth-first pre-order, as nodes()), the box tests
+        that passed.  Returns (passes per node, rays, box tests)."""
+        L = lib()
+        L.orc_node_stats_enable.argtypes = [C.c_int, C.c_int]
+        L.orc_node_passes.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.orc_node_stats_enable(self.h, 1)
+        try:
+            _, cnt = self.render(ns, threads=threads)
+            n = len(self.nodes())
+            p = np.zeros(n, np.uint64)
+            L.orc_node_passes(self.h, p.ctypes.data, n)
+        finally:
+            L.orc_node_stats_enable(self.h, 0)
+        return p.astype(np.float64), cnt["rays"], cnt["box_tests"]
+
     def census(self) -> dict:
         c = np.zeros(12, np.int32)
         lib().orc_scene_census(self.h, c.ctypes.data)

@@ -132,3 +132,50 @@ def test_ppm_texture_loader(art, tmp_path):
         f.write(b"P6\n# comment\n4 3\n255\n" + rgb.tobytes())
     data, w, h = art.load_ppm(str(p))
     assert (w, h) == (4, 3) and np.array_equal(data, rgb)
+
+
+@pytest.mark.parametrize("name,nx,ny,ns", [("bouncing", 96, 64, 2), ("cornell", 48, 48, 4), ("final", 40, 40, 2)])
+def test_walk_array_planner(art, orc, name, nx, ny, ns):
+    """rt_scene_create's planner (host only): which interior nodes of the reference's tree to drop.  With
+    the oracle's own per-node pass counts as input, (1) its "before" figure is the oracle's box-test counter exactly -- the
+    cost model (a node is visited as often as its parent passes) is the reference walk's; (2) every leaf survives, in
+    order, with its box and object; (3) skip links still move forward; (4) the predicted tests after are what a replay of
+    the model over the kept nodes gives, and fewer than before."""
+    img, iw, ih = art.default_texture(name)
+    hs = art.HostScene(name, nx, ny, img, iw, ih)
+    nodes = hs.nodes()
+    o = orc.OracleScene(name, nx, ny, img, iw, ih)
+    passes, rays, box_tests = o.node_passes(ns, threads=4)
+    assert len(passes) == len(nodes)
+    walk, before, after = art.plan_walk_array(nodes, passes, rays)
+    assert abs(before * rays - box_tests) < 0.5, (before * rays, box_tests)
+    leaves = nodes[nodes["prim"] >= 0]
+    wleaves = walk[walk["prim"] >= 0]
+    assert len(wleaves) == len(leaves)
+    for f in ("prim", "bmin", "bmax"):
+        assert np.array_equal(wleaves[f], leaves[f]), f
+    assert (walk["skip"] > np.arange(len(walk))).all() and walk["skip"].max() == len(walk)
+    # which reference nodes were kept: they appear in the walk array in the old order
+    kept = np.zeros(len(nodes), bool)
+    j = 0
+    for w in walk:
+        while not (np.array_equal(nodes[j]["bmin"], w["bmin"]) and np.array_equal(nodes[j]["bmax"], w["bmax"]) and nodes[j]["prim"] == w["prim"]):
+            j += 1
+        kept[j] = True
+        j += 1
+    # replay the cost model: a kept node is visited as often as its nearest kept ancestor passes
+    total = 0.0
+    stack = []          # (end of subtree, passes of the nearest kept ancestor for nodes inside it)
+    for i, n in enumerate(nodes):
+        while stack and stack[-1][0] <= i:
+            stack.pop()
+        visits = stack[-1][1] if stack else float(rays)
+        if kept[i]:
+            total += visits
+        if n["prim"] < 0:
+            stack.append((int(n["skip"]), passes[i] if kept[i] else visits))
+    assert abs(total / rays - after) < 1e-9 * max(1.0, after), (total / rays, after)
+    assert after < before
+    # by surface area (no counts): still every leaf, in order
+    walk_sa, _, _ = art.plan_walk_array(nodes)
+    assert np.array_equal(walk_sa[walk_sa["prim"] >= 0]["prim"], leaves["prim"])
