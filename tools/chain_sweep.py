@@ -5,15 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import accelerated_ray_tracer_amd as art
 ns = int(sys.argv[1]); cfgs = sys.argv[2:]
-DEF = {"kernel": 3, "lpt": 1, "sparse_stride": 8, "heavy_factor_x10": 40, "heavy_max_tiles": 0, "tier1_pixels": 256, "tier1_factor_x10": 70, "split_samples": 32, "sparse_wg_percent": 35, "sparse_eager": 0, "sparse_priority": 3, "steps_per_trip": 12, "shade_threshold": 32, "newpath_threshold": 24, "diel_threshold": 2, "box_threshold": 8, "medium_threshold": 16, "threads": 512, "wg_per_cu": 2, "lds_mode": -1}
 art.init(0)
 hs = art.HostScene("random_scene", 1200, 800); ds = art.DeviceScene(hs)
 buf = torch.zeros((800, 1200, 3), dtype=torch.float32, device="cuda")
 for c in cfgs:
-    o = dict(DEF)
+    art.reset_options()
     for kv in c.split(","):
-        if kv: k, v = kv.split("="); o[k] = int(v)
-    for k, v in o.items(): art.set_option(k, v)
+        if kv: k, v = kv.split("="); art.set_option(k, int(v))
     best = 1e9
     for _ in range(2):
         _, sb = ds.render(hs.frame(ns=ns, tile_rows=8, tile_first=51, tile_stride=10**6), out=buf.data_ptr(), blocking=True); best = min(best, sb.ms_render)
