@@ -521,6 +521,15 @@ rt_status measure_pass_counts(rt_scene* s, std::vector<double>& pass, double& ra
     return st;
 }
 
+// a node array in the device's link encoding (rt_device.h, RT_NODE_SKIP)
+void device_nodes(const rt_node* nodes, size_t n, std::vector<rt_node>& out) {
+    out.assign(nodes, nodes + n);
+    for (size_t i = 0; i < n; ++i) {
+        out[i].skip = ~out[i].skip;
+        if (out[i].prim < 0) out[i].prim = ~(int32_t)(i + 1);
+    }
+}
+
 // builds the walk array (see "Collapse" above) and points dev.nodes at it
 rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
     const int n = d->n_nodes;
@@ -546,7 +555,9 @@ rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
     const std::vector<rt_node> walk = build_walk_array(d->nodes, n, plan.keep);
     if ((int)walk.size() == n) return RT_OK;
     const rt_node* d_walk = nullptr;
-    const rt_status st = upload(walk.data(), walk.size(), &d_walk);
+    std::vector<rt_node> enc;
+    device_nodes(walk.data(), walk.size(), enc);
+    const rt_status st = upload(enc.data(), enc.size(), &d_walk);
     if (st != RT_OK) return st;
     s->allocs.push_back(const_cast<void*>(static_cast<const void*>(d_walk)));
     s->dev.nodes = d_walk; s->dev.n_nodes = (int32_t)walk.size();
@@ -582,7 +593,6 @@ rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_sce
     rt_status st = validate(d, so, tx, uv);
     if (st != RT_OK) return st;
 
-#define UPSRC_nodes_ref nodes
 #define UPSRC_spheres spheres
 #define UPSRC_quads quads
 #define UPSRC_boxes boxes
@@ -602,7 +612,13 @@ rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_sce
         if (st != RT_OK) { rt_scene_destroy(s); return st; }                         \
         s->allocs.push_back(const_cast<void*>(static_cast<const void*>(s->dev.field))); \
     } while (0)
-    UP(nodes_ref, d->n_nodes);
+    {
+        std::vector<rt_node> enc;
+        device_nodes(d->nodes, (size_t)d->n_nodes, enc);
+        st = upload(enc.data(), enc.size(), &s->dev.nodes_ref);
+        if (st != RT_OK) { rt_scene_destroy(s); return st; }
+        s->allocs.push_back(const_cast<void*>(static_cast<const void*>(s->dev.nodes_ref)));
+    }
     UP(spheres, d->n_spheres);
     {   // quads and boxes: mark the axis-aligned ones (quad_test_axis, rt_device_funcs.h).  A quad qualifies when its unit
         // normal is exactly +-e_C and u, v, w each have exactly one non-zero component on the fitting axes; a box when its

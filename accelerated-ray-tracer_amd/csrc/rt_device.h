@@ -76,6 +76,12 @@ struct rt_rank_params {
                                          // >= heavy: in the list at all; >= sparse: tier 2; >= tier1 / tier0: those tiers
 };
 
+// Device encoding of a node's two links (both node arrays below; rt_abi.hip device_nodes()): `skip` holds ~skip and
+// `prim` holds ~(own index + 1) at an interior node (still < 0) and the object id (>= 0) at a leaf.  The walk's "where
+// next" is then ~((pass && prim < 0) ? prim : skip) -- one select, one NOT -- and the staged kernel's stopped state
+// ~skip is the stored word itself.
+#define RT_NODE_SKIP(stored) (~(stored))
+
 // device-resident scene: the rt_scene_desc arrays after upload
 struct rt_scene_dev {
     const rt_node* nodes;        // the walk array: the reference's tree in depth-first order, interior nodes that do not pay removed (rt_abi.hip, "collapse")

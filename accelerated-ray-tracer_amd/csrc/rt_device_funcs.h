@@ -665,7 +665,7 @@ DEV bool trace(const SceneView& sc, const Ray& r, HitInfo& best, unsigned int* p
     const int n = sc.n_nodes;
     while (i < n) {
         const float4 a = nodes4[2 * i], b = nodes4[2 * i + 1];
-        int next = __float_as_int(a.w);   // skip link
+        int next = RT_NODE_SKIP(__float_as_int(a.w));   // skip link
         if (slab_test(a, b, r.o, inv, tmin, best.t)) {
             if (pass_count) atomicAdd(&pass_count[i], 1u);   // calibration pass only (rt_abi.hip, "collapse")
             const int32_t prim = __float_as_int(b.w);
@@ -702,7 +702,7 @@ DEV bool trace_wide(const SceneView& sc, const Ray& r, HitInfo& best) {
         const bool valid = idx < n;
         const float4 a = nodes4[2 * (valid ? idx : 0)], b = nodes4[2 * (valid ? idx : 0) + 1];
         const bool pass = valid && slab_test(a, b, r.o, inv, tmin, best.t);
-        const int my_skip = __float_as_int(a.w), my_prim = __float_as_int(b.w);
+        const int my_skip = RT_NODE_SKIP(__float_as_int(a.w)), my_prim = __float_as_int(b.w);
         const unsigned long long pass_mask = __ballot(pass);
         const unsigned long long leaf_mask = __ballot(valid && my_prim >= 0);
         const int end = (i + 64 < n) ? i + 64 : n;

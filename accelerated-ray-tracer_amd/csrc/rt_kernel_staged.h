@@ -1,5 +1,8 @@
 // rt_kernel_staged.h -- kernel 3 ("staged"), the kernel that ships; instantiated by rt_staged_*.hip.
 #pragma once
+#ifndef RT_STEP_UNROLL
+#define RT_STEP_UNROLL 2
+#endif
 #include "rt_device_funcs.h"
 
 // =============================================================================
@@ -218,7 +221,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                 for (int k = 0; k < n_nodes; ++k) {
                     const float4 a = nodes4[2 * k], b = nodes4[2 * k + 1];
                     const int32_t prim = __builtin_amdgcn_readfirstlane(__float_as_int(b.w));
-                    const int skip = __builtin_amdgcn_readfirstlane(__float_as_int(a.w));
+                    const int skip = RT_NODE_SKIP(__builtin_amdgcn_readfirstlane(__float_as_int(a.w)));
                     const bool active = scanning && k >= resume;
                     DIAG_ADD(1, 1); DIAG_ADD(2, __popcll(__ballot(active)));
                     const bool pass = active && (ref_form ? slab_test(a, b, cur.o, inv, tmin, best.t) : slab_test_finite(a, b, cur.o, inv, tmin, best.t));
@@ -244,23 +247,29 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
         // stage B keeps exactly the reference's.  Rays with a zero direction component (no monotonicity: 0 * inf) stop
         // at every leaf, as before.
         if (__ballot(!finite_inv && (unsigned)node < (unsigned)n_nodes) == 0ull) {
-            const int trip_steps = sparse ? 2 * fp.steps_per_trip : fp.steps_per_trip;
-            for (int step = 0; step < trip_steps; ++step) {
-                // nobody left walking (all stopped or finished): end the trip now -- this is what keeps the latency of
-                // a wave's last few live lanes near one node step per step (end of frame, small multi-GPU partitions)
+            // two node steps per check: "nobody left walking" (all stopped or finished) ends the trip -- this is what
+            // keeps the latency of a wave's last few live lanes near one node step per step (end of frame, small
+            // multi-GPU partitions); checking every other step halves the loop's scalar overhead
+            const int trip_pairs = ((sparse ? 2 * fp.steps_per_trip : fp.steps_per_trip) + RT_STEP_UNROLL - 1) / RT_STEP_UNROLL;
+            for (int pair = 0; pair < trip_pairs; ++pair) {
                 if (__ballot((unsigned)node < (unsigned)n_nodes) == 0ull) break;
-                DIAG_ADD(1, 1); DIAG_ADD(2, __popcll(__ballot((unsigned)node < (unsigned)n_nodes)));
-                if ((unsigned)node < (unsigned)n_nodes) {
-                    const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
-                    const bool pass = slab_test_finite(a, b, cur.o, inv, tmin, best.t);
-                    const int32_t prim = __float_as_int(b.w);
-                    const int skip = __float_as_int(a.w);
-                    const bool at_leaf = pass && prim >= 0;
-                    const bool stop = at_leaf && pend >= 0;
-                    const int next = (pass && prim < 0) ? node + 1 : skip;
-                    pend = (at_leaf && pend < 0) ? node : pend;
-                    parked = stop ? node : parked;
-                    node = stop ? ~next : next;
+#pragma unroll
+                for (int half = 0; half < RT_STEP_UNROLL; ++half) {
+                    DIAG_ADD(1, 1); DIAG_ADD(2, __popcll(__ballot((unsigned)node < (unsigned)n_nodes)));
+                    if ((unsigned)node < (unsigned)n_nodes) {
+                        const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
+                        const bool pass = slab_test_finite(a, b, cur.o, inv, tmin, best.t);
+                        // device encoding of the links (rt_device.h, RT_NODE_SKIP): a.w = ~skip, b.w = ~(node + 1) for
+                        // an interior node and the object id (>= 0) at a leaf -- "where next" is one select and one
+                        // NOT, and the stopped form ~skip is a.w as stored
+                        const int32_t link = __float_as_int(b.w), nskip = __float_as_int(a.w);
+                        const bool at_leaf = pass && link >= 0;
+                        const bool stop = at_leaf && pend >= 0;
+                        const int next = ~((pass && link < 0) ? link : nskip);
+                        pend = (at_leaf && pend < 0) ? node : pend;
+                        parked = stop ? node : parked;
+                        node = stop ? nskip : next;
+                    }
                 }
             }
         } else {   // a lane's ray has a zero direction component: the reference's own slab form for this trip
@@ -269,14 +278,13 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                 if ((unsigned)node < (unsigned)n_nodes) {
                     const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
                     const bool pass = slab_test(a, b, cur.o, inv, tmin, best.t);
-                    const int32_t prim = __float_as_int(b.w);
-                    const int skip = __float_as_int(a.w);
-                    const bool at_leaf = pass && prim >= 0;
+                    const int32_t link = __float_as_int(b.w), nskip = __float_as_int(a.w);
+                    const bool at_leaf = pass && link >= 0;
                     const bool stop = at_leaf && (pend >= 0 || !finite_inv);
-                    const int next = (pass && prim < 0) ? node + 1 : skip;
+                    const int next = ~((pass && link < 0) ? link : nskip);
                     pend = (at_leaf && !stop) ? node : pend;
                     parked = stop ? node : parked;
-                    node = stop ? ~next : next;
+                    node = stop ? nskip : next;
                 }
             }
         }

@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
                             const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
                             const bool pass = slab_test_finite(a, b, o, inv, tmin, best.t);
                             const int32_t prim = __float_as_int(b.w);
-                            const int skip = __float_as_int(a.w);
+                            const int skip = RT_NODE_SKIP(__float_as_int(a.w));
                             const bool at_leaf = pass && prim >= 0;
                             const int next = (pass && prim < 0) ? node + 1 : skip;
                             parked = at_leaf ? prim : parked;
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(1024) rt_render_wavefront_kernel(rt_scene_dev 
                             const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
                             const bool pass = slab_test(a, b, o, inv, tmin, best.t);
                             const int32_t prim = __float_as_int(b.w);
-                            const int skip = __float_as_int(a.w);
+                            const int skip = RT_NODE_SKIP(__float_as_int(a.w));
                             const bool at_leaf = pass && prim >= 0;
                             const int next = (pass && prim < 0) ? node + 1 : skip;
                             parked = at_leaf ? prim : parked;
