@@ -123,6 +123,20 @@ DEV bool sphere_test(const rt_sphere& s, const Ray& r, float tmin, float tmax, f
     return sphere_test_a(s, r, dot(r.d, r.d), tmin, tmax, t_out);
 }
 
+// A record whose address is the same in every lane (scan mode, tier loops), read through the constant address space:
+// the scene arrays are written by the host before the launch and never by a kernel, so the load may go through the
+// scalar cache into SGPRs (s_load_dwordx*) instead of 64 identical vector loads.
+template <typename T>
+DEV T uniform_load(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "records are whole dwords");
+    typedef const __attribute__((address_space(4))) uint32_t* const_words;
+    const const_words w = (const_words)(unsigned long long)p;
+    union { T value; uint32_t words[sizeof(T) / 4]; } u;
+#pragma unroll
+    for (unsigned int k = 0; k < sizeof(T) / 4; ++k) u.words[k] = w[k];
+    return u.value;
+}
+
 // quad::hit (quad.cuh:60-90); inclusive bounds
 DEV bool quad_test(const rt_quad& q, const Ray& r, float tmin, float tmax, float& t_out) {
     const f3 n = ld3(q.n);
@@ -189,31 +203,35 @@ DEV bool simple_test(const SceneView& sc, int32_t ref, const Ray& r, float tmin,
     if (kind == RT_PRIM_QUAD) {
         leaf = ref;
         if (UNIFORM) {
-            const int code = __builtin_amdgcn_readfirstlane(quad_axis_code(sc.quads[idx]));
-            if (code == 1) return quad_test_axis<0>(sc.quads[idx], r, tmin, tmax, t_out);
-            if (code == 2) return quad_test_axis<1>(sc.quads[idx], r, tmin, tmax, t_out);
-            if (code == 3) return quad_test_axis<2>(sc.quads[idx], r, tmin, tmax, t_out);
+            const rt_quad q = uniform_load(sc.quads + idx);
+            const int code = quad_axis_code(q);
+            if (code == 1) return quad_test_axis<0>(q, r, tmin, tmax, t_out);
+            if (code == 2) return quad_test_axis<1>(q, r, tmin, tmax, t_out);
+            if (code == 3) return quad_test_axis<2>(q, r, tmin, tmax, t_out);
+            return quad_test(q, r, tmin, tmax, t_out);
         }
         return quad_test(sc.quads[idx], r, tmin, tmax, t_out);
     }
     // box
-    const int first_raw = sc.boxes[idx].first_quad, first = first_raw & 0x3FFFFFFF;
+    const int first_raw = UNIFORM ? uniform_load(&sc.boxes[idx].first_quad) : sc.boxes[idx].first_quad, first = first_raw & 0x3FFFFFFF;
     bool any = false;
     float closest = tmax;
+    // a face record: through the scalar cache when the box is the same in every lane
+    auto face = [&](int f) -> rt_quad { return UNIFORM ? uniform_load(sc.quads + first + f) : sc.quads[first + f]; };
     if (first_raw & 0x40000000) {
         // make_box's faces in its order (front, right, back, left, top, bottom): normals along z, x, z, x, y, y -- verified
         // per box by rt_scene_create
         float t;
-        if (quad_test_axis<2>(sc.quads[first + 0], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 0); }
-        if (quad_test_axis<0>(sc.quads[first + 1], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 1); }
-        if (quad_test_axis<2>(sc.quads[first + 2], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 2); }
-        if (quad_test_axis<0>(sc.quads[first + 3], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 3); }
-        if (quad_test_axis<1>(sc.quads[first + 4], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 4); }
-        if (quad_test_axis<1>(sc.quads[first + 5], r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 5); }
+        if (quad_test_axis<2>(face(0), r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 0); }
+        if (quad_test_axis<0>(face(1), r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 1); }
+        if (quad_test_axis<2>(face(2), r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 2); }
+        if (quad_test_axis<0>(face(3), r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 3); }
+        if (quad_test_axis<1>(face(4), r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 4); }
+        if (quad_test_axis<1>(face(5), r, tmin, closest, t)) { any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + 5); }
     } else {
         for (int f = 0; f < 6; ++f) {
             float t;
-            if (quad_test(sc.quads[first + f], r, tmin, closest, t)) {
+            if (quad_test(face(f), r, tmin, closest, t)) {
                 any = true; closest = t; leaf = RT_PRIM_REF(RT_PRIM_QUAD, first + f);
             }
         }
@@ -240,7 +258,7 @@ template <bool UNIFORM = false>
 DEV bool solid_test(const SceneView& sc, int32_t ref, const Ray& r, float tmin, float tmax, float& t_out, int32_t& leaf, int32_t& inst) {
     if (RT_PRIM_KIND(ref) == RT_PRIM_INSTANCE) {
         inst = RT_PRIM_INDEX(ref);
-        const rt_instance in = sc.instances[inst];
+        const rt_instance in = UNIFORM ? uniform_load(sc.instances + inst) : sc.instances[inst];
         const Ray q = to_object_space(in, r);
         return simple_test<UNIFORM>(sc, in.child, q, tmin, tmax, t_out, leaf);
     }
@@ -287,7 +305,8 @@ DEV void leaf_test(const SceneView& sc, int32_t ref, const Ray& r, float tmin, H
     }
     int32_t leaf = ref, inst = -1;
     if (RT_PRIM_KIND(ref) == RT_PRIM_MEDIUM) {
-        if (medium_test<UNIFORM>(sc, sc.media[RT_PRIM_INDEX(ref)], r, tmin, best.t, t)) { best.t = t; best.prim = ref; best.inst = -1; }
+        const rt_medium m = UNIFORM ? uniform_load(sc.media + RT_PRIM_INDEX(ref)) : sc.media[RT_PRIM_INDEX(ref)];
+        if (medium_test<UNIFORM>(sc, m, r, tmin, best.t, t)) { best.t = t; best.prim = ref; best.inst = -1; }
         return;
     }
     if (solid_test<UNIFORM>(sc, ref, r, tmin, best.t, t, leaf, inst)) { best.t = t; best.prim = leaf; best.inst = inst; }

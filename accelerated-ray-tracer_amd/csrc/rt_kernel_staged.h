@@ -219,7 +219,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                 const bool ref_form = __ballot(scanning && !finite_inv) != 0ull;   // a zero direction component somewhere: aabb.cuh's own form for all
                 int resume = 0;                                            // this lane skips nodes below this index
                 for (int k = 0; k < n_nodes; ++k) {
-                    const float4 a = nodes4[2 * k], b = nodes4[2 * k + 1];
+                    const float4 a = uniform_load(nodes4 + 2 * k), b = uniform_load(nodes4 + 2 * k + 1);
                     const int32_t prim = __builtin_amdgcn_readfirstlane(__float_as_int(b.w));
                     const int skip = RT_NODE_SKIP(__builtin_amdgcn_readfirstlane(__float_as_int(a.w)));
                     const bool active = scanning && k >= resume;
