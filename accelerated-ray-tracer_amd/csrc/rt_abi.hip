@@ -497,6 +497,7 @@ rt_status measure_pass_counts(rt_scene* s, std::vector<double>& pass, double& ra
     rt_frame_params fp;
     memset(&fp, 0, sizeof(fp));
     fp.fb = d_fb; fp.ray_counter = s->d_ray_counter; fp.work_counter = s->d_work_counter; fp.node_pass = d_pass;
+    fp.node_pass_lds = (size_t)n * sizeof(unsigned int) <= 48u * 1024u ? 1 : 0;
     fp.seed_base = 1984; fp.nx = nx; fp.ny = ny; fp.ns = 4; fp.gamma = 1.0f;
     fp.tile_rows = ny; fp.tile_first = 0; fp.tile_stride = 1; fp.local_rows = ny;
     fp.tiles_x = (nx + 7) / 8;

@@ -103,6 +103,7 @@ struct rt_frame_params {
     unsigned long long* ray_counter;      // += rays traced
     unsigned int* work_counter;           // persistent kernel's pixel queue head
     unsigned int* node_pass;              // calibration pass (kernel 0 only): += 1 per box test of nodes_ref[i] that passed; null otherwise
+    int32_t node_pass_lds;                // ... collected in LDS per workgroup (n_nodes_ref x 4 B of dynamic LDS) and flushed at its end
     const unsigned int* tile_order;       // optional: 8x8 tiles in descending cost (LPT order); null = natural order
     unsigned int* tile_cost;              // first part of a split frame: rays per 8x8 tile
     rt_pixel_state* state_out;            // first part of a split frame: where pixels are parked (the frame is not written)

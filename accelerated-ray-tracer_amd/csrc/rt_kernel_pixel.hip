@@ -12,6 +12,16 @@ __global__ void __launch_bounds__(256) rt_render_pixel_kernel(rt_scene_dev sd, r
     SceneView sc = stage_scene<LDS_MODE>(sd, lds);
     sc.nodes = sd.nodes_ref; sc.n_nodes = sd.n_nodes_ref;   // every node of the reference's tree, straight from memory
 
+    // calibration pass (rt_abi.hip, "collapse"): the per-node pass counts are collected in LDS and added to memory once
+    // per workgroup -- a scene of 19 nodes would otherwise funnel every lane's atomics into 19 addresses
+    unsigned int* node_pass = fp.node_pass;
+    unsigned int* lds_pass = reinterpret_cast<unsigned int*>(lds);
+    const bool pass_in_lds = fp.node_pass != nullptr && fp.node_pass_lds != 0;     // grid-uniform
+    if (pass_in_lds) {
+        for (int k = (int)threadIdx.x; k < sd.n_nodes_ref; k += (int)blockDim.x) lds_pass[k] = 0u;
+        __syncthreads();
+        node_pass = lds_pass;
+    }
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     int i, lrow;
     unsigned long long rays = 0;
@@ -28,7 +38,7 @@ __global__ void __launch_bounds__(256) rt_render_pixel_kernel(rt_scene_dev sd, r
             for (int bounce = 0; bounce < 50; ++bounce) {
                 HitInfo h;
                 ++rays;
-                if (!trace<SPHERES_ONLY>(sc, cur, h, fp.node_pass)) {
+                if (!trace<SPHERES_ONLY>(sc, cur, h, node_pass)) {
                     radiance = fma3(throughput, miss_color(fp, cur), radiance);
                     break;
                 }
@@ -45,6 +55,11 @@ __global__ void __launch_bounds__(256) rt_render_pixel_kernel(rt_scene_dev sd, r
         }
         store_pixel(fp, i, lrow, col);
     }
+    if (pass_in_lds) {
+        __syncthreads();
+        for (int k = (int)threadIdx.x; k < sd.n_nodes_ref; k += (int)blockDim.x)
+            if (lds_pass[k] != 0u) atomicAdd(&fp.node_pass[k], lds_pass[k]);
+    }
     // one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
     if ((threadIdx.x & 63) == 0 && rays) atomicAdd(fp.ray_counter, rays);
@@ -55,7 +70,8 @@ __global__ void __launch_bounds__(256) rt_render_pixel_kernel(rt_scene_dev sd, r
 namespace {
 template <bool SO, int TX, bool UV>
 hipError_t launch_pixel(const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block, hipStream_t st) {
-    hipLaunchKernelGGL((rt_render_pixel_kernel<SO, TX, UV, 0>), grid, block, 0, st, sd, fp);
+    const size_t lds = (fp.node_pass != nullptr && fp.node_pass_lds != 0) ? (size_t)sd.n_nodes_ref * sizeof(unsigned int) : 0;
+    hipLaunchKernelGGL((rt_render_pixel_kernel<SO, TX, UV, 0>), grid, block, lds, st, sd, fp);
     return hipGetLastError();
 }
 }  // namespace
