@@ -43,7 +43,7 @@ struct rt_options {
     int diel_threshold = 2;
     int box_threshold = 8;
     int medium_threshold = 16;
-    int newpath_threshold = 24;
+    int newpath_threshold = 0;   // lanes waiting for a new path before stage E runs; 0 = by kernel family: 24 spheres-only, 8 general (measured: Book-2 final 382 -> 364 ms with 8, Book-1 32.2 -> 35.1)
     int sparse_stride = 8;      // lanes per pixel in sparse waves (64 / live lanes); 0 disables sparse waves
     int split_samples = 32;      // samples per pixel rendered before pixels are ranked by measured cost
     int tier0_auto = 1;          // size the tiers from the share of the frame this call renders (see rank_pixels); 0 = the knobs as set
@@ -421,7 +421,7 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "box_threshold") { if (value < 1 || value > 64) return invalid("box_threshold: 1..64"); g_opt.box_threshold = value; }
     else if (k == "medium_threshold") { if (value < 1 || value > 64) return invalid("medium_threshold: 1..64"); g_opt.medium_threshold = value; }
     else if (k == "diel_threshold") { if (value < 1 || value > 64) return invalid("diel_threshold: 1..64"); g_opt.diel_threshold = value; }
-    else if (k == "newpath_threshold") { if (value < 1 || value > 64) return invalid("newpath_threshold: 1..64"); g_opt.newpath_threshold = value; }
+    else if (k == "newpath_threshold") { if (value < 0 || value > 64) return invalid("newpath_threshold: 0 (by kernel family) or 1..64"); g_opt.newpath_threshold = value; }
     else if (k == "sparse_stride") { if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return invalid("sparse_stride: 0, 2, 4, ... 64"); g_opt.sparse_stride = value; }
     else if (k == "sparse_factor_x10") { if (value < 10 || value > 1000) return invalid("sparse_factor_x10: 10..1000"); g_opt.sparse_factor_x10 = value; }
     else if (k == "heavy_factor_x10") { if (value < 10 || value > 1000) return invalid("heavy_factor_x10: 10..1000"); g_opt.heavy_factor_x10 = value; }
@@ -847,7 +847,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     fp.leaf_threshold = g_opt.leaf_threshold;
     fp.diel_threshold = g_opt.diel_threshold;
     fp.box_threshold = g_opt.box_threshold; fp.medium_threshold = g_opt.medium_threshold;
-    fp.newpath_threshold = g_opt.newpath_threshold;
+    fp.newpath_threshold = g_opt.newpath_threshold > 0 ? g_opt.newpath_threshold : (s->spheres_only ? 24 : 8);
 
     // LDS residency: nodes + spheres in every workgroup of a CU if they fit that many times (2 workgroups for the lean
     // spheres-only kernels, 3 otherwise: see the workgroup shapes below), else once (one big workgroup per CU), else nodes only
