@@ -781,6 +781,14 @@ rt_status rt_debug_counters(rt_scene* s, unsigned long long* out16) {
     HIPCHK(hipMemcpy(out16, s->d_ray_counter + 1, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RT_OK;
 }
+// Diagnostic builds: cycles the waves of the frame spent per part of the staged kernel's loop, summed over waves
+// ([0] box steps, [1] object tests, [2] stage C, [3] D, [4] E, [6] stage gating, [7] stage F + loop; s_memtime units).
+rt_status rt_debug_stage_cycles(rt_scene* s, unsigned long long* out8) {
+    if (!s || !out8) return invalid("null argument");
+    { const rt_status ud = use_device(s->device); if (ud != RT_OK) return ud; }
+    HIPCHK(hipMemcpy(out8, s->d_ray_counter + 17, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
 // Diagnostic builds: when the waves of the LAST launch ended, as two histograms of RT_DIAG_BINS bins of 1 ms after the first
 // wave's start (ordinary waves, then waves that started in sparse / tier mode).
 rt_status rt_debug_wave_ends(rt_scene* s, unsigned long long* out, int n) {

@@ -32,8 +32,10 @@
 // Diagnostic build only (-DRT_DIAG): per-stage execution counts, written to fp.diag (never to an output).
 #ifdef RT_DIAG
 #define DIAG_ADD(slot, value) do { const unsigned long long v_ = (unsigned long long)(value); if ((threadIdx.x & 63) == 0) diag_local[slot] += v_; } while (0)
+#define DIAG_T(slot) do { const unsigned long long n_ = __builtin_readcyclecounter(); diag_time[slot] += n_ - diag_t_last; diag_t_last = n_; } while (0)
 #else
 #define DIAG_ADD(slot, value) do { } while (0)
+#define DIAG_T(slot) do { } while (0)
 #endif
 
 template <bool SPHERES_ONLY, int TEX, bool NEED_UV, int LDS_MODE>
@@ -41,6 +43,8 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef RT_DIAG
     unsigned long long diag_local[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long diag_time[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long diag_t_last = 0;
     const unsigned long long diag_t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz
     if ((threadIdx.x & 63) == 0) atomicMin(fp.ray_counter + RT_DIAG_T0_SLOT, diag_t_start);
     unsigned long long diag_fetch_t = 0ull, diag_done_t = 0ull;   // when this lane took its last pixel / ran out of work
@@ -210,8 +214,12 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
         else __builtin_amdgcn_s_setprio(3);
     }
 
+#ifdef RT_DIAG
+    diag_t_last = __builtin_readcyclecounter();
+#endif
     for (;;) {
         DIAG_ADD(0, 1);
+        DIAG_T(7);
         if (SCAN) {
             // ---------------- stages A + B, scan form (see LDS_MODE 4 above)
             const bool scanning = (unsigned)node < (unsigned)n_nodes;      // a ray set up in stage F and not yet traced
@@ -227,9 +235,12 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                     const bool pass = active && (ref_form ? slab_test(a, b, cur.o, inv, tmin, best.t) : slab_test_finite(a, b, cur.o, inv, tmin, best.t));
                     if (prim < 0) {
                         if (active && !pass) resume = skip;
+                        DIAG_T(0);
                     } else if (__ballot(pass) != 0ull) {
+                        DIAG_T(0);
                         DIAG_ADD(3, 1); DIAG_ADD(4, __popcll(__ballot(pass)));
                         if (pass) leaf_test<SPHERES_ONLY, true>(sc, prim, cur, tmin, best);
+                        DIAG_T(1);
                     }
                 }
                 if (scanning) node = ST_DONE;
@@ -288,6 +299,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                 }
             }
         }
+        DIAG_T(0);
         // ---------------- stage B: leaf pass -- one object test per lane that has one due (the earliest noted leaf).
         // A lane stopped at a second leaf resumes with that one noted; if its walk ends right there and nobody else can
         // step either, the pass runs again at once (a wave must never reach the stage logic below with a test due and
@@ -356,6 +368,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
             break;
         }
         }
+        DIAG_T(1);
         // a finished walk that hit nothing (main.cu:57-68) needs no stage: add the background and end the path now
         if (node == ST_DONE && pend < 0 && best.prim < 0) {
             radiance = fma3(throughput, miss_color(fp, cur), radiance);
@@ -373,6 +386,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
         const int newpath_need = 1 + ((fp.newpath_threshold - 1) * live >> 6);
         const bool eager = sparse && fp.sparse_eager;     // sparse waves trade their own throughput for latency
 
+        DIAG_T(6);
         // ---------------- stage C: classify + resolve + diffuse/metal/isotropic scatter
         if (n_done > 0 && (n_done >= shade_need || force || eager)) {
             ran_stage = true;
@@ -427,6 +441,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                 }
             }
         }
+        DIAG_T(2);
         // ---------------- stage D: dielectric scatter (material.cuh:119-159)
         {
             const int n_diel = __popcll(__ballot(node == ST_DIEL));
@@ -442,6 +457,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                 }
             }
         }
+        DIAG_T(3);
         // ---------------- stage E: path end -> next sample / next pixel -> camera ray (main.cu:119-132)
         {
             const int n_new = __popcll(__ballot(node == ST_NEWPATH));
@@ -531,6 +547,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                 }
             }
         }
+        DIAG_T(4);
         // ---------------- stage F: per-ray setup
         if (ran_stage) {
             DIAG_ADD(12, 1); DIAG_ADD(13, __popcll(__ballot(node == ST_SETUP)));
@@ -556,6 +573,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
 #ifdef RT_DIAG
     if ((threadIdx.x & 63) == 0) {
         for (int k = 0; k < 16; ++k) atomicAdd(fp.ray_counter + 1 + k, diag_local[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(fp.ray_counter + 17 + k, diag_time[k]);
         const unsigned long long t0 = *reinterpret_cast<volatile unsigned long long*>(fp.ray_counter + RT_DIAG_T0_SLOT);
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
         unsigned long long bin = now > t0 ? (now - t0) / 100000ull : 0ull;   // 1 ms bins
