@@ -72,6 +72,30 @@ def test_scene_matches_oracle(gpu, orc, name, nx, ny, ns):
     assert_frames_equal(fb, ref, name)
 
 
+@pytest.mark.parametrize("name,ny", [("bouncing", 171), ("cornell", 256), ("final", 256)])
+def test_calibration_pass_counts_are_the_oracles(gpu, orc, name, ny):
+    """rt_scene_create measures, per node of the reference's tree, how often its box test passes (kernel 0 with counters
+    on, a 256-pixel-wide 4-spp frame through the scene's camera, seeds 1984 + pixel; collected in LDS per workgroup).  The
+    same frame through the oracle must give the same counts, because the traversal is the same to the bit: checked
+    through what the planner derives from them -- its box tests per ray before the collapse equal the oracle's counter,
+    and the walk array it builds from the oracle's counts on the host has the size the device built."""
+    nx = 256                                                                       # the calibration frame of a scene of this aspect
+    img, iw, ih = gpu.default_texture(name)
+    hs = gpu.HostScene(name, nx, ny, img, iw, ih)
+    gpu.reset_options()
+    ds = gpu.DeviceScene(hs)
+    try:
+        info = ds.walk_info()
+    finally:
+        ds.close()
+    o = orc.OracleScene(name, nx, ny, img, iw, ih)
+    passes, rays, box_tests = o.node_passes(4, threads=8)
+    assert abs(info["tests_before"] * rays - box_tests) < 0.5, (info["tests_before"] * rays, box_tests)
+    walk, before, after = gpu.plan_walk_array(hs.nodes(), passes, rays)
+    assert len(walk) == info["nodes_walked"], (len(walk), info)
+    assert abs(after - info["tests_after"]) < 1e-9 * max(1.0, after)
+
+
 @pytest.mark.parametrize("name,nx,ny,ns", [("bouncing", 160, 96, 8), ("cornell", 64, 64, 8), ("cornell_smoke", 64, 64, 8), ("final", 64, 64, 4), ("degenerate", 32, 16, 8)])
 def test_walk_array_is_invisible(gpu, orc, name, nx, ny, ns):
     """rt_scene_create drops the interior nodes of the reference's tree whose box test does not pay (option bvh_collapse:
