@@ -72,7 +72,7 @@ MATERIAL_DTYPE = np.dtype([("kind", "<i4"), ("tex", "<i4"), ("fuzz", "<f4"), ("i
 RT_ABI_SYMBOLS = ["rt_init", "rt_shutdown", "rt_strerror", "rt_last_hip_error", "rt_last_error_detail", "rt_scene_create",
                   "rt_scene_destroy", "rt_frame_local_rows", "rt_local_to_global_row", "rt_render", "rt_frame_finish",
                   "rt_set_option", "rt_reset_options", "rt_scene_walk_info", "rt_init_devices", "rt_multi_create", "rt_multi_render",
-                  "rt_multi_destroy", "rt_multi_device_count", "rt_multi_row_owner", "rt_plan_walk_array"]
+                  "rt_multi_destroy", "rt_multi_device_count", "rt_multi_row_owner", "rt_plan_walk_array", "rt_regroup_leaves"]
 
 _rt = None
 _host = None
@@ -137,6 +137,8 @@ def rt_lib():
         L.rt_multi_row_owner.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.rt_plan_walk_array.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.rt_regroup_leaves.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.rt_regroup_leaves.restype = C.c_int
         L.rt_scene_walk_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _rt = L
     return _rt
@@ -348,6 +350,15 @@ def plan_walk_array(nodes: np.ndarray, passes=None, root_visits: float = 0.0):
     _check(rt_lib().rt_plan_walk_array(nodes.ctypes.data, n, None if p is None else p.ctypes.data, float(root_visits), out.ctypes.data, n,
                                        C.byref(n_out), C.byref(tb), C.byref(ta)), "rt_plan_walk_array")
     return out[: n_out.value].copy(), tb.value, ta.value
+
+
+def regroup_leaves(nodes: np.ndarray) -> np.ndarray:
+    """The leaves of `nodes` (NODE_DTYPE) under a binary tree built by surface-area cost over the same leaf order.  Host only."""
+    nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
+    out = np.zeros(2 * len(nodes), NODE_DTYPE)
+    n_out = C.c_int32(0)
+    _check(rt_lib().rt_regroup_leaves(nodes.ctypes.data, len(nodes), out.ctypes.data, len(out), C.byref(n_out)), "rt_regroup_leaves")
+    return out[: n_out.value].copy()
 
 
 def row_owner(global_row: int, tile_rows: int, n_gpus: int):

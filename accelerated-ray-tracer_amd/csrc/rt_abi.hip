@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -63,8 +64,9 @@ struct rt_options {
     int sparse_eager = 0;
     int sparse_work_percent = 5;  // tiers 0-2 hold at most this share of the frame's work (rays so far); dearer-than-average pixels beyond it go to tier 3
     int sparse_wg_percent = 35;   // at most this share of the workgroups starts in sparse mode
-    int bvh_collapse = 2;        // walk array (rt_scene_create): 0 = the reference's tree as is, 1 = interior nodes that do not pay
-                                 // removed, decided from box surface areas, 2 = decided from pass counts measured on a small frame
+    int bvh_collapse = 3;        // walk array (rt_scene_create): 0 = the reference's tree as is, 1 = interior nodes that do not pay
+                                 // removed, decided from box surface areas, 2 = decided from pass counts measured on a small frame,
+                                 // 3 = as 2, and the leaves regrouped by surface-area cost if that predicts fewer box tests
     int scan_nodes = 24;         // scenes whose walk array has at most this many nodes are scanned in lockstep (lds_mode 4); 0 = never
     int multi_force_rccl = 0;    // rt_multi_render: go through the RCCL gather even with one device (tests the path on a one-GPU box)
     int lpt = 1;                 // cost prepass + longest-first tile order (staged kernel, ns >= 2 * split_samples)
@@ -347,6 +349,79 @@ std::vector<rt_node> build_walk_array(const rt_node* nodes, int n, const std::ve
     return walk;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "Regroup": another hierarchy over the same leaves.
+//
+// By the argument above the walk returns what the reference's returns as long as (1) the leaves -- the reference's
+// single-object nodes, with their boxes -- come in the reference's depth-first order and (2) every interior box contains
+// the boxes below it: then "a leaf's own box passes" still implies that everything above it passed, and a subtree is
+// only ever skipped when none of its leaves could have passed.  Which contiguous runs of leaves are grouped is free.  The
+// reference groups by halving (bvh.cuh:25-36), which puts a huge object (the ground sphere: a 2000-unit box) into half of
+// the top of the tree: every box above it is as large as it is and always passes.  regroup_leaves() builds a binary tree
+// over the same leaf sequence by surface-area cost -- split [a, b) at the k that minimises area(a..k) * (k - a) +
+// area(k..b) * (b - k) -- with interior boxes = the exact union (float min / max) of their leaves' boxes.  The result
+// goes through the same calibration pass and collapse DP as the reference's tree, and whichever walk array predicts
+// fewer box tests per ray is used (bvh_collapse = 3).
+// ---------------------------------------------------------------------------------------------------------------
+std::vector<rt_node> regroup_leaves(const rt_node* nodes, int n) {
+    std::vector<rt_node> leaves;
+    for (int i = 0; i < n; ++i) if (nodes[i].prim >= 0) leaves.push_back(nodes[i]);
+    const int m = (int)leaves.size();
+    std::vector<rt_node> out;
+    if (m == 0) return out;
+    out.reserve((size_t)(2 * m));
+    struct box { float lo[3], hi[3]; };
+    auto grow = [](box& b, const rt_node& l) { for (int a = 0; a < 3; ++a) { b.lo[a] = fminf(b.lo[a], l.bmin[a]); b.hi[a] = fmaxf(b.hi[a], l.bmax[a]); } };
+    auto area = [](const box& b) -> double {
+        const double x = fmax(0.0, (double)b.hi[0] - b.lo[0]), y = fmax(0.0, (double)b.hi[1] - b.lo[1]), z = fmax(0.0, (double)b.hi[2] - b.lo[2]);
+        return 2.0 * (x * y + y * z + x * z);
+    };
+    const box empty = {{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+    std::vector<double> right_area((size_t)m + 1);
+    // explicit stack: (a, b) ranges in depth-first order; the interior node's skip link is patched when its range ends
+    struct item { int a, b; };
+    std::vector<item> todo;
+    todo.push_back({0, m});
+    std::vector<std::pair<int, int>> open;   // (index of an interior node, number of leaves still to be emitted under it)
+    auto leaf_done = [&]() {
+        // every enclosing interior node has one leaf fewer to wait for; those that are complete end here
+        for (auto& o : open) --o.second;
+        while (!open.empty() && open.back().second == 0) { out[(size_t)open.back().first].skip = (int32_t)out.size(); open.pop_back(); }
+    };
+    while (!todo.empty()) {
+        const item it = todo.back();
+        todo.pop_back();
+        if (it.b - it.a == 1) {
+            rt_node l = leaves[(size_t)it.a];
+            l.skip = (int32_t)out.size() + 1;
+            out.push_back(l);
+            leaf_done();
+            continue;
+        }
+        box all = empty;
+        for (int k = it.a; k < it.b; ++k) grow(all, leaves[(size_t)k]);
+        // areas of the right parts [k, b), then sweep the left part
+        box r = empty;
+        for (int k = it.b - 1; k > it.a; --k) { grow(r, leaves[(size_t)k]); right_area[(size_t)k] = area(r); }
+        box l = empty;
+        int best_k = (it.a + it.b) / 2;
+        double best = -1.0;
+        for (int k = it.a + 1; k < it.b; ++k) {
+            grow(l, leaves[(size_t)k - 1]);
+            const double c = area(l) * (double)(k - it.a) + right_area[(size_t)k] * (double)(it.b - k);
+            if (std::isfinite(c) && (best < 0.0 || c < best)) { best = c; best_k = k; }
+        }
+        rt_node nd;
+        for (int a = 0; a < 3; ++a) { nd.bmin[a] = all.lo[a]; nd.bmax[a] = all.hi[a]; }
+        nd.prim = -1; nd.skip = 0;
+        open.push_back({(int)out.size(), it.b - it.a});
+        out.push_back(nd);
+        todo.push_back({best_k, it.b});      // right part second
+        todo.push_back({it.a, best_k});      // left part first
+    }
+    return out;
+}
+
 }  // namespace
 
 extern "C" {
@@ -441,7 +516,7 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "sparse_work_percent") { if (value < 0 || value > 100) return invalid("sparse_work_percent: 0..100"); g_opt.sparse_work_percent = value; }
     else if (k == "sparse_wg_percent") { if (value < 1 || value > 100) return invalid("sparse_wg_percent: 1..100"); g_opt.sparse_wg_percent = value; }
     else if (k == "heavy_max_tiles") { if (value < 0 || value > 4096) return invalid("heavy_max_tiles: 0..4096"); g_opt.heavy_max_tiles = value; }
-    else if (k == "bvh_collapse") { if (value < 0 || value > 2) return invalid("bvh_collapse: 0, 1 or 2 (read by rt_scene_create)"); g_opt.bvh_collapse = value; }
+    else if (k == "bvh_collapse") { if (value < 0 || value > 3) return invalid("bvh_collapse: 0..3 (read by rt_scene_create)"); g_opt.bvh_collapse = value; }
     else if (k == "scan_nodes") { if (value < 0 || value > 64) return invalid("scan_nodes: 0..64"); g_opt.scan_nodes = value; }
     else if (k == "multi_force_rccl") { if (value < 0 || value > 1) return invalid("multi_force_rccl: 0 or 1"); g_opt.multi_force_rccl = value; }
     else if (k == "lpt") { if (value < 0 || value > 1) return invalid("lpt: 0 or 1"); g_opt.lpt = value; }
@@ -479,7 +554,7 @@ rt_status rt_scene_destroy(rt_scene* s) {
 
 namespace {
 // Pass counts of the reference's nodes on a small frame through the scene's own camera (kernel 0 with its counters on).
-rt_status measure_pass_counts(rt_scene* s, std::vector<double>& pass, double& rays) {
+rt_status measure_pass_counts(rt_scene* s, const rt_node* d_tree, int n_tree, std::vector<double>& pass, double& rays) {
     const rt_camera& c = s->dev.camera;
     const double hw = sqrt((double)c.horizontal[0] * c.horizontal[0] + (double)c.horizontal[1] * c.horizontal[1] + (double)c.horizontal[2] * c.horizontal[2]);
     const double vh = sqrt((double)c.vertical[0] * c.vertical[0] + (double)c.vertical[1] * c.vertical[1] + (double)c.vertical[2] * c.vertical[2]);
@@ -488,7 +563,9 @@ rt_status measure_pass_counts(rt_scene* s, std::vector<double>& pass, double& ra
     int nx = aspect >= 1.0 ? 256 : (int)(256 * aspect + 0.5), ny = aspect >= 1.0 ? (int)(256 / aspect + 0.5) : 256;
     if (nx < 8) nx = 8;
     if (ny < 8) ny = 8;
-    const int n = s->dev.n_nodes_ref;
+    const int n = n_tree;
+    rt_scene_dev dev = s->dev;
+    dev.nodes_ref = d_tree; dev.n_nodes_ref = n_tree;          // the tree kernel 0 walks in this pass
     unsigned int* d_pass = nullptr;
     float* d_fb = nullptr;
     HIPCHK(hipMalloc((void**)&d_pass, (size_t)n * sizeof(unsigned int)));
@@ -509,7 +586,7 @@ rt_status measure_pass_counts(rt_scene* s, std::vector<double>& pass, double& ra
     do {
         if ((e = hipMemset(d_pass, 0, (size_t)n * sizeof(unsigned int))) != hipSuccess) break;
         if ((e = hipMemset(s->d_ray_counter, 0, RT_COUNTER_BYTES)) != hipSuccess) break;
-        if ((e = rt_launch_pixel(s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, dim3((fp.work_items + 255u) / 256u), dim3(256), nullptr)) != hipSuccess) break;
+        if ((e = rt_launch_pixel(s->spheres_only, s->tex_level, s->need_uv, dev, fp, dim3((fp.work_items + 255u) / 256u), dim3(256), nullptr)) != hipSuccess) break;
         if ((e = hipDeviceSynchronize()) != hipSuccess) break;
         if ((e = hipMemcpy(h.data(), d_pass, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost)) != hipSuccess) break;
         if ((e = hipMemcpy(&r, s->d_ray_counter, sizeof(r), hipMemcpyDeviceToHost)) != hipSuccess) break;
@@ -538,11 +615,12 @@ rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
     if (g_opt.bvh_collapse == 0 || n < 3) return RT_OK;
     std::vector<double> pass;
     double root_visits = 0.0;
-    if (g_opt.bvh_collapse == 2) {
-        const rt_status st = measure_pass_counts(s, pass, root_visits);
+    if (g_opt.bvh_collapse >= 2) {
+        const rt_status st = measure_pass_counts(s, s->dev.nodes_ref, n, pass, root_visits);
         if (st != RT_OK) return st;
     }
-    if (root_visits <= 0.0) {   // by surface area: a ray that passes a box passes a box inside it about in proportion to the areas
+    const bool measured = root_visits > 0.0;
+    if (!measured) {   // by surface area: a ray that passes a box passes a box inside it about in proportion to the areas
         pass.assign((size_t)n, 0.0);
         for (int i = 0; i < n; ++i) {
             const double ex = fmax(0.0, (double)d->nodes[i].bmax[0] - d->nodes[i].bmin[0]), ey = fmax(0.0, (double)d->nodes[i].bmax[1] - d->nodes[i].bmin[1]),
@@ -552,9 +630,35 @@ rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
         root_visits = pass[0];
     }
     collapse_plan plan;
-    if (!plan_collapse(d->nodes, n, pass, root_visits, plan)) return RT_OK;
-    const std::vector<rt_node> walk = build_walk_array(d->nodes, n, plan.keep);
-    if ((int)walk.size() == n) return RT_OK;
+    const bool planned = plan_collapse(d->nodes, n, pass, root_visits, plan);
+    std::vector<rt_node> walk;
+    if (planned) walk = build_walk_array(d->nodes, n, plan.keep);
+    bool changed = planned && (int)walk.size() != n;
+    // the regrouped hierarchy over the same leaves ("Regroup" above), through the same calibration pass and DP; it needs
+    // the reference's own tree to have passed the checks (a real tree, boxes containing their children's)
+    if (g_opt.bvh_collapse >= 3 && measured && planned) {
+        const std::vector<rt_node> tree = regroup_leaves(d->nodes, n);
+        const int m = (int)tree.size();
+        if (m >= 3) {
+            std::vector<rt_node> enc;
+            device_nodes(tree.data(), tree.size(), enc);
+            const rt_node* d_tree = nullptr;
+            rt_status st = upload(enc.data(), enc.size(), &d_tree);
+            if (st != RT_OK) return st;
+            std::vector<double> pass2;
+            double rays2 = 0.0;
+            st = measure_pass_counts(s, d_tree, m, pass2, rays2);
+            (void)hipFree(const_cast<rt_node*>(d_tree));
+            if (st != RT_OK) return st;
+            collapse_plan plan2;
+            if (rays2 == root_visits && plan_collapse(tree.data(), m, pass2, rays2, plan2) && plan2.tests_after < plan.tests_after) {
+                walk = build_walk_array(tree.data(), m, plan2.keep);
+                plan.tests_after = plan2.tests_after;            // "before" stays the reference tree's figure
+                changed = true;
+            }
+        }
+    }
+    if (!changed) return RT_OK;
     const rt_node* d_walk = nullptr;
     std::vector<rt_node> enc;
     device_nodes(walk.data(), walk.size(), enc);
@@ -721,6 +825,14 @@ rt_status rt_plan_walk_array(const rt_node* nodes, int32_t n, const double* pass
     if (tests_before) *tests_before = plan.tests_before;
     if (tests_after) *tests_after = plan.tests_after;
     if (out) for (int i = 0; i < (int)walk.size() && i < cap; ++i) out[i] = walk[i];
+    return RT_OK;
+}
+
+rt_status rt_regroup_leaves(const rt_node* nodes, int32_t n, rt_node* out, int32_t cap, int32_t* n_out) {
+    if (!nodes || n <= 0 || !n_out) return invalid("rt_regroup_leaves: bad argument");
+    const std::vector<rt_node> tree = regroup_leaves(nodes, n);
+    *n_out = (int32_t)tree.size();
+    if (out) for (int i = 0; i < (int)tree.size() && i < cap; ++i) out[i] = tree[i];
     return RT_OK;
 }
 

@@ -83,11 +83,13 @@ def test_calibration_pass_counts_are_the_oracles(gpu, orc, name, ny):
     img, iw, ih = gpu.default_texture(name)
     hs = gpu.HostScene(name, nx, ny, img, iw, ih)
     gpu.reset_options()
+    gpu.set_option("bvh_collapse", 2)                                             # the plan over the reference's own tree
     ds = gpu.DeviceScene(hs)
     try:
         info = ds.walk_info()
     finally:
         ds.close()
+        gpu.reset_options()
     o = orc.OracleScene(name, nx, ny, img, iw, ih)
     passes, rays, box_tests = o.node_passes(4, threads=8)
     assert abs(info["tests_before"] * rays - box_tests) < 0.5, (info["tests_before"] * rays, box_tests)
@@ -99,14 +101,15 @@ def test_calibration_pass_counts_are_the_oracles(gpu, orc, name, ny):
 @pytest.mark.parametrize("name,nx,ny,ns", [("bouncing", 160, 96, 8), ("cornell", 64, 64, 8), ("cornell_smoke", 64, 64, 8), ("final", 64, 64, 4), ("degenerate", 32, 16, 8)])
 def test_walk_array_is_invisible(gpu, orc, name, nx, ny, ns):
     """rt_scene_create drops the interior nodes of the reference's tree whose box test does not pay (option bvh_collapse:
-    0 = none, 1 = chosen by surface area, 2 = by measured pass counts).  Interior boxes never change what bvh_node::hit
+    0 = none, 1 = chosen by surface area, 2 = by measured pass counts, 3 = as 2 or a regrouping of the same leaves by
+    surface-area cost, whichever predicts fewer box tests).  Interior boxes never change what bvh_node::hit
     returns (bvh.cuh:95-106; see rt_abi.hip "Collapse"), so all three must give the oracle's frame and ray count, and the
     walk array must keep every leaf in the reference's order."""
     img, iw, ih = gpu.default_texture(name)
     hs = gpu.HostScene(name, nx, ny, img, iw, ih)
     ref, cnt = orc.OracleScene(name, nx, ny, img, iw, ih).render(ns)
     sizes = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         gpu.reset_options()
         gpu.set_option("bvh_collapse", mode)
         ds = gpu.DeviceScene(hs)

@@ -179,3 +179,40 @@ def test_walk_array_planner(art, orc, name, nx, ny, ns):
     # by surface area (no counts): still every leaf, in order
     walk_sa, _, _ = art.plan_walk_array(nodes)
     assert np.array_equal(walk_sa[walk_sa["prim"] >= 0]["prim"], leaves["prim"])
+
+
+@pytest.mark.parametrize("name,nx,ny", [("bouncing", 240, 160), ("cornell", 120, 120), ("final", 100, 100), ("two_spheres", 200, 100)])
+def test_regrouped_hierarchy_keeps_what_exactness_needs(art, name, nx, ny):
+    """rt_regroup_leaves (host only): a different hierarchy over the reference's leaves.  The walk gives the
+    reference's results as long as (1) the leaves -- boxes, objects, order -- are the reference's and (2) every interior box
+    contains every box below it; checked here for every node, together with the array's shape (a binary tree in depth-first
+    order, skip links to the end of each subtree, interior box = exactly the union of its leaves' boxes)."""
+    img, iw, ih = art.default_texture(name)
+    hs = art.HostScene(name, nx, ny, img, iw, ih)
+    nodes = hs.nodes()
+    tree = art.regroup_leaves(nodes)
+    leaves = nodes[nodes["prim"] >= 0]
+    tleaf = tree["prim"] >= 0
+    assert len(tree) == 2 * len(leaves) - 1
+    for f in ("prim", "bmin", "bmax"):
+        assert np.array_equal(tree[tleaf][f], leaves[f]), f
+    n = len(tree)
+    assert (tree["skip"] > np.arange(n)).all() and tree["skip"][0] == n
+    leaf_pos = np.flatnonzero(tleaf)
+    for i in range(n):
+        end = int(tree["skip"][i])
+        if tleaf[i]:
+            assert end == i + 1
+            continue
+        # two children tiling the subtree
+        c1 = i + 1
+        c2 = int(tree["skip"][c1])
+        assert c2 < end and int(tree["skip"][c2]) == end
+        inside = leaf_pos[(leaf_pos > i) & (leaf_pos < end)]
+        assert len(inside) >= 2
+        assert np.array_equal(tree["bmin"][i], tree["bmin"][inside].min(axis=0)) and np.array_equal(tree["bmax"][i], tree["bmax"][inside].max(axis=0))
+        sub = slice(i + 1, end)
+        assert (tree["bmin"][sub] >= tree["bmin"][i]).all() and (tree["bmax"][sub] <= tree["bmax"][i]).all()
+    # it goes through the planner like the reference's tree does (by surface area here: no device)
+    walk, before, after = art.plan_walk_array(tree)
+    assert np.array_equal(walk[walk["prim"] >= 0]["prim"], leaves["prim"]) and after <= before
