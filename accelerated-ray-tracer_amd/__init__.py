@@ -137,7 +137,7 @@ def rt_lib():
         L.rt_multi_row_owner.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.rt_plan_walk_array.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
-        L.rt_regroup_leaves.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.rt_regroup_leaves.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.rt_regroup_leaves.restype = C.c_int
         L.rt_scene_walk_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _rt = L
@@ -352,12 +352,13 @@ def plan_walk_array(nodes: np.ndarray, passes=None, root_visits: float = 0.0):
     return out[: n_out.value].copy(), tb.value, ta.value
 
 
-def regroup_leaves(nodes: np.ndarray) -> np.ndarray:
-    """The leaves of `nodes` (NODE_DTYPE) under a binary tree built by surface-area cost over the same leaf order.  Host only."""
+def regroup_leaves(nodes: np.ndarray, method: int = 0) -> np.ndarray:
+    """The leaves of `nodes` (NODE_DTYPE) under another binary tree over the same leaf order (method 0 = top-down by
+    surface-area cost, 1 = bottom-up).  Host only."""
     nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
     out = np.zeros(2 * len(nodes), NODE_DTYPE)
     n_out = C.c_int32(0)
-    _check(rt_lib().rt_regroup_leaves(nodes.ctypes.data, len(nodes), out.ctypes.data, len(out), C.byref(n_out)), "rt_regroup_leaves")
+    _check(rt_lib().rt_regroup_leaves(nodes.ctypes.data, len(nodes), int(method), out.ctypes.data, len(out), C.byref(n_out)), "rt_regroup_leaves")
     return out[: n_out.value].copy()
 
 

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <utility>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -358,12 +359,13 @@ std::vector<rt_node> build_walk_array(const rt_node* nodes, int n, const std::ve
 // only ever skipped when none of its leaves could have passed.  Which contiguous runs of leaves are grouped is free.  The
 // reference groups by halving (bvh.cuh:25-36), which puts a huge object (the ground sphere: a 2000-unit box) into half of
 // the top of the tree: every box above it is as large as it is and always passes.  regroup_leaves() builds a binary tree
-// over the same leaf sequence by surface-area cost -- split [a, b) at the k that minimises area(a..k) * (k - a) +
-// area(k..b) * (b - k) -- with interior boxes = the exact union (float min / max) of their leaves' boxes.  The result
-// goes through the same calibration pass and collapse DP as the reference's tree, and whichever walk array predicts
-// fewer box tests per ray is used (bvh_collapse = 3).
+// over the same leaf sequence, interior boxes = the exact union (float min / max) of their leaves' boxes, in one of two
+// ways: top-down -- split [a, b) at the k that minimises area(a..k) * (k - a) + area(k..b) * (b - k) -- or bottom-up --
+// keep merging the two neighbouring groups with the smallest union.  Each goes through the same calibration pass and
+// collapse DP as the reference's tree, and whichever walk array predicts the fewest box tests per ray is used
+// (bvh_collapse = 3).
 // ---------------------------------------------------------------------------------------------------------------
-std::vector<rt_node> regroup_leaves(const rt_node* nodes, int n) {
+std::vector<rt_node> regroup_leaves(const rt_node* nodes, int n, int method) {
     std::vector<rt_node> leaves;
     for (int i = 0; i < n; ++i) if (nodes[i].prim >= 0) leaves.push_back(nodes[i]);
     const int m = (int)leaves.size();
@@ -377,6 +379,68 @@ std::vector<rt_node> regroup_leaves(const rt_node* nodes, int n) {
         return 2.0 * (x * y + y * z + x * z);
     };
     const box empty = {{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+    if (method == 1) {
+        // bottom-up: merge, again and again, the two neighbouring groups whose union has the smallest surface area (a heap
+        // of neighbour pairs with lazy deletion); the huge leaf is merged last and ends up directly under the root
+        struct group { box b; int left, right, leaf, prev, next, count; bool alive; };
+        std::vector<group> g((size_t)m);
+        for (int i = 0; i < m; ++i) {
+            g[(size_t)i].b = empty; grow(g[(size_t)i].b, leaves[(size_t)i]);
+            g[(size_t)i].left = g[(size_t)i].right = -1; g[(size_t)i].leaf = i; g[(size_t)i].prev = i - 1; g[(size_t)i].next = i + 1 < m ? i + 1 : -1;
+            g[(size_t)i].count = 1; g[(size_t)i].alive = true;
+        }
+        auto unite = [](const box& x, const box& y) { box u = x; for (int a = 0; a < 3; ++a) { u.lo[a] = fminf(u.lo[a], y.lo[a]); u.hi[a] = fmaxf(u.hi[a], y.hi[a]); } return u; };
+        struct pair_key { double area; int i, j; };
+        auto worse = [](const pair_key& x, const pair_key& y) { return x.area > y.area || (x.area == y.area && x.i > y.i); };
+        std::vector<pair_key> heap;
+        auto push = [&](int i, int j) {
+            double ar = area(unite(g[(size_t)i].b, g[(size_t)j].b));
+            if (!std::isfinite(ar)) ar = DBL_MAX;
+            heap.push_back({ar, i, j});
+            std::push_heap(heap.begin(), heap.end(), worse);
+        };
+        for (int i = 0; i + 1 < m; ++i) push(i, i + 1);
+        int root = m - 1;
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), worse);
+            const pair_key k = heap.back();
+            heap.pop_back();
+            if (!g[(size_t)k.i].alive || !g[(size_t)k.j].alive) continue;
+            group u;
+            u.b = unite(g[(size_t)k.i].b, g[(size_t)k.j].b); u.left = k.i; u.right = k.j; u.leaf = -1;
+            u.prev = g[(size_t)k.i].prev; u.next = g[(size_t)k.j].next; u.count = g[(size_t)k.i].count + g[(size_t)k.j].count; u.alive = true;
+            g[(size_t)k.i].alive = g[(size_t)k.j].alive = false;
+            const int id = (int)g.size();
+            g.push_back(u);
+            root = id;
+            if (u.prev >= 0) { g[(size_t)u.prev].next = id; push(u.prev, id); }
+            if (u.next >= 0) { g[(size_t)u.next].prev = id; push(id, u.next); }
+        }
+        // emit depth-first
+        std::vector<int> todo2;
+        todo2.push_back(root);
+        std::vector<std::pair<int, int>> open2;
+        while (!todo2.empty()) {
+            const int id = todo2.back();
+            todo2.pop_back();
+            if (g[(size_t)id].leaf >= 0) {
+                rt_node l = leaves[(size_t)g[(size_t)id].leaf];
+                l.skip = (int32_t)out.size() + 1;
+                out.push_back(l);
+                for (auto& o : open2) --o.second;
+                while (!open2.empty() && open2.back().second == 0) { out[(size_t)open2.back().first].skip = (int32_t)out.size(); open2.pop_back(); }
+                continue;
+            }
+            rt_node nd;
+            for (int a = 0; a < 3; ++a) { nd.bmin[a] = g[(size_t)id].b.lo[a]; nd.bmax[a] = g[(size_t)id].b.hi[a]; }
+            nd.prim = -1; nd.skip = 0;
+            open2.push_back({(int)out.size(), g[(size_t)id].count});
+            out.push_back(nd);
+            todo2.push_back(g[(size_t)id].right);
+            todo2.push_back(g[(size_t)id].left);
+        }
+        return out;
+    }
     std::vector<double> right_area((size_t)m + 1);
     // explicit stack: (a, b) ranges in depth-first order; the interior node's skip link is patched when its range ends
     struct item { int a, b; };
@@ -637,9 +701,10 @@ rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
     // the regrouped hierarchy over the same leaves ("Regroup" above), through the same calibration pass and DP; it needs
     // the reference's own tree to have passed the checks (a real tree, boxes containing their children's)
     if (g_opt.bvh_collapse >= 3 && measured && planned) {
-        const std::vector<rt_node> tree = regroup_leaves(d->nodes, n);
-        const int m = (int)tree.size();
-        if (m >= 3) {
+        for (int method = 0; method < 2; ++method) {
+            const std::vector<rt_node> tree = regroup_leaves(d->nodes, n, method);
+            const int m = (int)tree.size();
+            if (m < 3) continue;
             std::vector<rt_node> enc;
             device_nodes(tree.data(), tree.size(), enc);
             const rt_node* d_tree = nullptr;
@@ -828,9 +893,9 @@ rt_status rt_plan_walk_array(const rt_node* nodes, int32_t n, const double* pass
     return RT_OK;
 }
 
-rt_status rt_regroup_leaves(const rt_node* nodes, int32_t n, rt_node* out, int32_t cap, int32_t* n_out) {
-    if (!nodes || n <= 0 || !n_out) return invalid("rt_regroup_leaves: bad argument");
-    const std::vector<rt_node> tree = regroup_leaves(nodes, n);
+rt_status rt_regroup_leaves(const rt_node* nodes, int32_t n, int32_t method, rt_node* out, int32_t cap, int32_t* n_out) {
+    if (!nodes || n <= 0 || !n_out || method < 0 || method > 1) return invalid("rt_regroup_leaves: bad argument");
+    const std::vector<rt_node> tree = regroup_leaves(nodes, n, method);
     *n_out = (int32_t)tree.size();
     if (out) for (int i = 0; i < (int)tree.size() && i < cap; ++i) out[i] = tree[i];
     return RT_OK;

@@ -207,10 +207,11 @@ rt_status rt_plan_walk_array(const rt_node* nodes, int32_t n, const double* pass
                              int32_t* n_out, double* tests_before, double* tests_after);
 
 /* Another hierarchy over the same leaves, host only: the leaves of `nodes` (its single-object nodes, boxes and order
- * untouched) grouped into a binary tree by surface-area cost, interior boxes = the union of their leaves' boxes.  Any such
- * tree gives the reference's results; rt_scene_create (bvh_collapse = 3) measures this one beside the
- * reference's and walks whichever needs fewer box tests.  out holds up to cap nodes; *n_out = 2 * leaves - 1. */
-rt_status rt_regroup_leaves(const rt_node* nodes, int32_t n, rt_node* out, int32_t cap, int32_t* n_out);
+ * untouched) under a binary tree whose interior boxes are the union of their leaves' boxes; method 0 = top-down by
+ * surface-area cost, 1 = bottom-up (merge the neighbouring groups with the smallest union).  Any such tree gives the
+ * reference's results; rt_scene_create (bvh_collapse = 3) measures both beside the reference's tree and
+ * walks whichever needs the fewest box tests.  out holds up to cap nodes; *n_out = 2 * leaves - 1. */
+rt_status rt_regroup_leaves(const rt_node* nodes, int32_t n, int32_t method, rt_node* out, int32_t cap, int32_t* n_out);
 
 /* Number of rows a frame description assigns to this call, and the mapping
  * from a compact local row to its global row. */

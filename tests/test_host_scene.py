@@ -181,8 +181,9 @@ def test_walk_array_planner(art, orc, name, nx, ny, ns):
     assert np.array_equal(walk_sa[walk_sa["prim"] >= 0]["prim"], leaves["prim"])
 
 
+@pytest.mark.parametrize("method", [0, 1])
 @pytest.mark.parametrize("name,nx,ny", [("bouncing", 240, 160), ("cornell", 120, 120), ("final", 100, 100), ("two_spheres", 200, 100)])
-def test_regrouped_hierarchy_keeps_what_exactness_needs(art, name, nx, ny):
+def test_regrouped_hierarchy_keeps_what_exactness_needs(art, name, nx, ny, method):
     """rt_regroup_leaves (host only): a different hierarchy over the reference's leaves.  The walk gives the
     reference's results as long as (1) the leaves -- boxes, objects, order -- are the reference's and (2) every interior box
     contains every box below it; checked here for every node, together with the array's shape (a binary tree in depth-first
@@ -190,7 +191,7 @@ def test_regrouped_hierarchy_keeps_what_exactness_needs(art, name, nx, ny):
     img, iw, ih = art.default_texture(name)
     hs = art.HostScene(name, nx, ny, img, iw, ih)
     nodes = hs.nodes()
-    tree = art.regroup_leaves(nodes)
+    tree = art.regroup_leaves(nodes, method)
     leaves = nodes[nodes["prim"] >= 0]
     tleaf = tree["prim"] >= 0
     assert len(tree) == 2 * len(leaves) - 1
