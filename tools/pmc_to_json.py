@@ -18,7 +18,7 @@ KERNEL = "rt_render_staged_kernel"
 
 def find(sub, pat):
     g = glob.glob(os.path.join(d, sub, "**", pat), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None   # a reused tag leaves older runs beside the new one: take the newest
 
 
 def per_frame(sub):

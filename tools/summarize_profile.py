@@ -5,7 +5,7 @@ import csv, glob, os, sys, collections
 d = sys.argv[1]
 def find(sub, pat):
     g = glob.glob(os.path.join(d, sub, "**", pat), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None   # a reused tag leaves older runs beside the new one: take the newest
 ks = find("trace", "*kernel_stats.csv")
 if ks:
     print("== kernel-trace --stats (", os.path.relpath(ks, d), ")")
