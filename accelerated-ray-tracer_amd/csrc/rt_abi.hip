@@ -361,11 +361,12 @@ std::vector<rt_node> build_walk_array(const rt_node* nodes, int n, const std::ve
 // the top of the tree: every box above it is as large as it is and always passes.  regroup_leaves() builds a binary tree
 // over the same leaf sequence, interior boxes = the exact union (float min / max) of their leaves' boxes, in one of two
 // ways: top-down -- split [a, b) at the k that minimises area(a..k) * (k - a) + area(k..b) * (b - k) -- or bottom-up --
-// keep merging the two neighbouring groups with the smallest union.  Each goes through the same calibration pass and
-// collapse DP as the reference's tree, and whichever walk array predicts the fewest box tests per ray is used
-// (bvh_collapse = 3).
+// keep merging the two neighbouring groups with the smallest union, "smallest" by surface area (method 1) or by how many
+// of ~4000 rays sampled from the calibration pass meet it (method 2: the scene as this camera's paths see it).  Each goes
+// through the same calibration pass and collapse DP as the reference's tree, and whichever walk array predicts the fewest
+// box tests per ray is used (bvh_collapse = 3).
 // ---------------------------------------------------------------------------------------------------------------
-std::vector<rt_node> regroup_leaves(const rt_node* nodes, int n, int method) {
+std::vector<rt_node> regroup_leaves(const rt_node* nodes, int n, int method, const std::vector<float>* sample = nullptr) {
     std::vector<rt_node> leaves;
     for (int i = 0; i < n; ++i) if (nodes[i].prim >= 0) leaves.push_back(nodes[i]);
     const int m = (int)leaves.size();
@@ -379,9 +380,33 @@ std::vector<rt_node> regroup_leaves(const rt_node* nodes, int n, int method) {
         return 2.0 * (x * y + y * z + x * z);
     };
     const box empty = {{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
-    if (method == 1) {
+    if (method >= 1) {
         // bottom-up: merge, again and again, the two neighbouring groups whose union has the smallest surface area (a heap
-        // of neighbour pairs with lazy deletion); the huge leaf is merged last and ends up directly under the root
+        // of neighbour pairs with lazy deletion); the huge leaf is merged last and ends up directly under the root.
+        // method 2: "smallest" by the share of the calibration pass's sampled rays that pass the union box (each with the
+        // limit it ended with) -- the scene as this camera's paths see it -- with the surface area as the tie-break
+        const size_t n_rays = (method == 2 && sample) ? sample->size() / 7 : 0;
+        // the sample as seven arrays (origin, 1 / direction, limit) so that the loop below vectorises
+        std::vector<float> q[7];
+        for (int a = 0; a < 7; ++a) q[a].resize(n_rays);
+        for (size_t r = 0; r < n_rays; ++r) {
+            for (int a = 0; a < 3; ++a) { q[a][r] = (*sample)[r * 7 + a]; q[3 + a][r] = 1.0f / (*sample)[r * 7 + 3 + a]; }
+            q[6][r] = (*sample)[r * 7 + 6];
+        }
+        auto seen_by = [&](const box& b) -> double {
+            unsigned int hits = 0;
+            for (size_t r = 0; r < n_rays; ++r) {
+                float t0 = 0.001f, t1 = q[6][r];
+                for (int a = 0; a < 3; ++a) {
+                    const float x = (b.lo[a] - q[a][r]) * q[3 + a][r], y = (b.hi[a] - q[a][r]) * q[3 + a][r];
+                    const float lo_t = x < y ? x : y, hi_t = x < y ? y : x;
+                    t0 = lo_t > t0 ? lo_t : t0;
+                    t1 = hi_t < t1 ? hi_t : t1;
+                }
+                hits += (t1 <= t0) ? 0u : 1u;
+            }
+            return (double)hits;
+        };
         struct group { box b; int left, right, leaf, prev, next, count; bool alive; };
         std::vector<group> g((size_t)m);
         for (int i = 0; i < m; ++i) {
@@ -394,8 +419,10 @@ std::vector<rt_node> regroup_leaves(const rt_node* nodes, int n, int method) {
         auto worse = [](const pair_key& x, const pair_key& y) { return x.area > y.area || (x.area == y.area && x.i > y.i); };
         std::vector<pair_key> heap;
         auto push = [&](int i, int j) {
-            double ar = area(unite(g[(size_t)i].b, g[(size_t)j].b));
+            const box ub = unite(g[(size_t)i].b, g[(size_t)j].b);
+            double ar = area(ub);
             if (!std::isfinite(ar)) ar = DBL_MAX;
+            else if (n_rays) ar = seen_by(ub) + ar / (ar + 1.0);      // rays first, area (squashed below one ray) second
             heap.push_back({ar, i, j});
             std::push_heap(heap.begin(), heap.end(), worse);
         };
@@ -618,7 +645,7 @@ rt_status rt_scene_destroy(rt_scene* s) {
 
 namespace {
 // Pass counts of the reference's nodes on a small frame through the scene's own camera (kernel 0 with its counters on).
-rt_status measure_pass_counts(rt_scene* s, const rt_node* d_tree, int n_tree, std::vector<double>& pass, double& rays) {
+rt_status measure_pass_counts(rt_scene* s, const rt_node* d_tree, int n_tree, std::vector<double>& pass, double& rays, std::vector<float>* sample = nullptr, uint32_t sample_stride = 0) {
     const rt_camera& c = s->dev.camera;
     const double hw = sqrt((double)c.horizontal[0] * c.horizontal[0] + (double)c.horizontal[1] * c.horizontal[1] + (double)c.horizontal[2] * c.horizontal[2]);
     const double vh = sqrt((double)c.vertical[0] * c.vertical[0] + (double)c.vertical[1] * c.vertical[1] + (double)c.vertical[2] * c.vertical[2]);
@@ -647,6 +674,15 @@ rt_status measure_pass_counts(rt_scene* s, const rt_node* d_tree, int n_tree, st
     rt_status st = RT_OK;
     std::vector<unsigned int> h((size_t)n);
     unsigned long long r = 0;
+    enum { SAMPLE_CAP = 8192 };
+    float* d_sample = nullptr;
+    if (sample && sample_stride > 0) {
+        // every sample_stride-th ray of the pass (the caller knows how many there will be and keeps that below the
+        // capacity, so the SET of sampled rays does not depend on the order the lanes get there)
+        if (hipMalloc((void**)&d_sample, (size_t)SAMPLE_CAP * 7 * sizeof(float)) == hipSuccess) {
+            fp.ray_sample = d_sample; fp.ray_sample_cap = SAMPLE_CAP; fp.ray_sample_stride = sample_stride;
+        }
+    }
     do {
         if ((e = hipMemset(d_pass, 0, (size_t)n * sizeof(unsigned int))) != hipSuccess) break;
         if ((e = hipMemset(s->d_ray_counter, 0, RT_COUNTER_BYTES)) != hipSuccess) break;
@@ -654,8 +690,16 @@ rt_status measure_pass_counts(rt_scene* s, const rt_node* d_tree, int n_tree, st
         if ((e = hipDeviceSynchronize()) != hipSuccess) break;
         if ((e = hipMemcpy(h.data(), d_pass, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost)) != hipSuccess) break;
         if ((e = hipMemcpy(&r, s->d_ray_counter, sizeof(r), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if (d_sample) {
+            unsigned long long taken = 0;
+            if ((e = hipMemcpy(&taken, s->d_ray_counter + 2, sizeof(taken), hipMemcpyDeviceToHost)) != hipSuccess) break;
+            if (taken > SAMPLE_CAP) taken = SAMPLE_CAP;
+            sample->resize((size_t)taken * 7);
+            if (taken && (e = hipMemcpy(sample->data(), d_sample, (size_t)taken * 7 * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        }
     } while (0);
     (void)hipFree(d_pass); (void)hipFree(d_fb);
+    if (d_sample) (void)hipFree(d_sample);
     if (e != hipSuccess) { g_last_hip_error = (int)e; g_detail = std::string("calibration pass: ") + hipGetErrorString(e); st = RT_ERR_HIP; }
     pass.assign((size_t)n, 0.0);
     for (int i = 0; i < n; ++i) pass[i] = (double)h[i];
@@ -678,6 +722,7 @@ rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
     s->walk_tests_before = s->walk_tests_after = 0.0;
     if (g_opt.bvh_collapse == 0 || n < 3) return RT_OK;
     std::vector<double> pass;
+    std::vector<float> ray_sample;
     double root_visits = 0.0;
     if (g_opt.bvh_collapse >= 2) {
         const rt_status st = measure_pass_counts(s, s->dev.nodes_ref, n, pass, root_visits);
@@ -701,8 +746,9 @@ rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
     // the regrouped hierarchy over the same leaves ("Regroup" above), through the same calibration pass and DP; it needs
     // the reference's own tree to have passed the checks (a real tree, boxes containing their children's)
     if (g_opt.bvh_collapse >= 3 && measured && planned) {
-        for (int method = 0; method < 2; ++method) {
-            const std::vector<rt_node> tree = regroup_leaves(d->nodes, n, method);
+        for (int method = 0; method < 3; ++method) {
+            if (method == 2 && ray_sample.size() < 7 * 256) continue;
+            const std::vector<rt_node> tree = regroup_leaves(d->nodes, n, method, &ray_sample);
             const int m = (int)tree.size();
             if (m < 3) continue;
             std::vector<rt_node> enc;
@@ -712,11 +758,13 @@ rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
             if (st != RT_OK) return st;
             std::vector<double> pass2;
             double rays2 = 0.0;
-            st = measure_pass_counts(s, d_tree, m, pass2, rays2);
+            // the first of these passes also keeps ~4000 of its rays for method 2 (same frame, same rays in every pass)
+            st = measure_pass_counts(s, d_tree, m, pass2, rays2, method == 0 ? &ray_sample : nullptr, (uint32_t)(root_visits / 4096.0) + 1u);
             (void)hipFree(const_cast<rt_node*>(d_tree));
             if (st != RT_OK) return st;
             collapse_plan plan2;
-            if (rays2 == root_visits && plan_collapse(tree.data(), m, pass2, rays2, plan2) && plan2.tests_after < plan.tests_after) {
+            const bool ok2 = rays2 == root_visits && plan_collapse(tree.data(), m, pass2, rays2, plan2);
+            if (ok2 && plan2.tests_after < plan.tests_after) {
                 walk = build_walk_array(tree.data(), m, plan2.keep);
                 plan.tests_after = plan2.tests_after;            // "before" stays the reference tree's figure
                 changed = true;

@@ -104,6 +104,8 @@ struct rt_frame_params {
     unsigned int* work_counter;           // persistent kernel's pixel queue head
     unsigned int* node_pass;              // calibration pass (kernel 0 only): += 1 per box test of nodes_ref[i] that passed; null otherwise
     int32_t node_pass_lds;                // ... collected in LDS per workgroup (n_nodes_ref x 4 B of dynamic LDS) and flushed at its end
+    float* ray_sample;                    // calibration pass: every ray_sample_stride-th ray as (origin, direction, t of its hit or FLT_MAX), 7 floats each
+    uint32_t ray_sample_cap, ray_sample_stride;   // ... up to this many; the count is kept in ray_counter[2]
     const unsigned int* tile_order;       // optional: 8x8 tiles in descending cost (LPT order); null = natural order
     unsigned int* tile_cost;              // first part of a split frame: rays per 8x8 tile
     rt_pixel_state* state_out;            // first part of a split frame: where pixels are parked (the frame is not written)

@@ -38,7 +38,17 @@ __global__ void __launch_bounds__(256) rt_render_pixel_kernel(rt_scene_dev sd, r
             for (int bounce = 0; bounce < 50; ++bounce) {
                 HitInfo h;
                 ++rays;
-                if (!trace<SPHERES_ONLY>(sc, cur, h, node_pass)) {
+                const bool hit_something = trace<SPHERES_ONLY>(sc, cur, h, node_pass);
+                if (fp.ray_sample && (rays + (unsigned long long)w * 7ull) % fp.ray_sample_stride == 0ull) {
+                    // a sample of the pass's rays for the regrouping's view-dependent cost (rt_abi.hip, "Regroup")
+                    const unsigned long long at = atomicAdd(fp.ray_counter + 2, 1ull);
+                    if (at < fp.ray_sample_cap) {
+                        float* o = fp.ray_sample + at * 7ull;
+                        o[0] = cur.o.x; o[1] = cur.o.y; o[2] = cur.o.z; o[3] = cur.d.x; o[4] = cur.d.y; o[5] = cur.d.z;
+                        o[6] = hit_something ? h.t : FLT_MAX;
+                    }
+                }
+                if (!hit_something) {
                     radiance = fma3(throughput, miss_color(fp, cur), radiance);
                     break;
                 }
