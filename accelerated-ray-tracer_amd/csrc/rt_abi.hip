@@ -746,8 +746,13 @@ rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
     // the regrouped hierarchy over the same leaves ("Regroup" above), through the same calibration pass and DP; it needs
     // the reference's own tree to have passed the checks (a real tree, boxes containing their children's)
     if (g_opt.bvh_collapse >= 3 && measured && planned) {
+        // bounds on the planning time of very large scenes (the reference's have at most 1410 leaves): the top-down split is
+        // quadratic in the worst case, the sampled-ray key costs leaves x rays
+        int n_leaves = 0;
+        for (int i = 0; i < n; ++i) n_leaves += d->nodes[i].prim >= 0 ? 1 : 0;
         for (int method = 0; method < 3; ++method) {
-            if (method == 2 && ray_sample.size() < 7 * 256) continue;
+            if (method == 0 && n_leaves > 65536) continue;
+            if (method == 2 && (ray_sample.size() < 7 * 256 || n_leaves > 8192)) continue;
             const std::vector<rt_node> tree = regroup_leaves(d->nodes, n, method, &ray_sample);
             const int m = (int)tree.size();
             if (m < 3) continue;
