@@ -44,7 +44,7 @@ LDS_PEAK_B_PER_CLK_CU = 256.0   # MI355X_MICROARCH.md, LDS table (ds_read_b64 / 
 TILE_ROWS = 4
 
 
-def roofline(scene, nx, ny, ns, rays_step, kernel_ms):
+def roofline(scene, nx, ny, ns, rays_step, kernel_ms, frame_rays=None):
     """The roofline object of the JSON line.  The binding roof of this path is VALU issue (the scene is LDS-resident and
     compulsory HBM traffic is ~0.01 B/ray): achieved = VALU wave-instructions per second = the per-step instruction
     count of the committed rocprofv3 PMC record (profiles/pmc_<workload>.json, made by tools/profile_bench.sh +
@@ -70,10 +70,20 @@ def roofline(scene, nx, ny, ns, rays_step, kernel_ms):
         r.update({"bound": "hbm", "traffic": None, "kernel_ms": round(kernel_ms, 3),
                   "note": hbm["note"] + "; no PMC record for this workload under profiles/, so the binding VALU-issue roof is not evaluated"})
         return r
-    c = rec["per_step"]
+    c = dict(rec["per_step"])
+    # The record is one WHOLE frame on one GPU.  In an N-GPU run this rank traced rays_step of the frame's frame_rays rays:
+    # its share of the counted instructions is taken in proportion (rows differ in cost per ray, so this is an estimate;
+    # the N = 1 line is exact).
+    share = 1.0
+    if frame_rays and frame_rays > 0 and rays_step < frame_rays:
+        share = rays_step / float(frame_rays)
+        for k in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+            if k in c: c[k] = c[k] * share
     valu, lanes = c["SQ_INSTS_VALU"], c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"]
     achieved = valu / ksec / 1e9
     hbm_bytes = rec.get("hbm_bytes_per_step")
+    if hbm_bytes is not None and share < 1.0:
+        hbm_bytes = int(hbm_bytes * share)
     hbm.update({"traffic_bytes_per_step": hbm_bytes, "traffic_gbs": None if hbm_bytes is None else round(hbm_bytes / ksec / 1e9, 2)})
     import hashlib, glob
     h = hashlib.sha1()   # = `cat csrc/* | sha1sum`, what tools/profile_bench.sh recorded beside the counters
@@ -94,6 +104,7 @@ def roofline(scene, nx, ny, ns, rays_step, kernel_ms):
                  "bank_conflict_share_of_lds_cycles": round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 3) if "SQ_LDS_IDX_ACTIVE" in c else None},
          "hbm": hbm,
          "pmc_record": f"profiles/pmc_{key}.json", "pmc_record_is_of_this_build": rec.get("csrc_sha1") == h.hexdigest()[:16],
+         "share_of_the_record_frame": round(share, 4),
          "note": "instruction and byte counts per step come from the committed PMC record (rocprofv3 passes of this bench command); the time is this run's: the launches of the render kernel for one frame (three with the cost-aware schedule) plus the ranking kernels between them, HIP events on the launch stream"}
     return r
 
@@ -302,7 +313,7 @@ def main():
                                     else f"{args.scene} (reference scene function of that name, src/main.cu)") + f" {args.nx}x{args.ny} @ {args.ns} spp, seed 1984+pixel",
                        "rays_per_frame": int(total_rays), "parallelism": f"rows{world}" if world > 1 else "single",
                        "tile_rows": TILE_ROWS if world > 1 else args.ny},
-            "roofline": roofline(args.scene, args.nx, args.ny, args.ns, rays_step, kms),
+            "roofline": roofline(args.scene, args.nx, args.ny, args.ns, rays_step, kms, total_rays),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.scene, args.nx, args.ny, args.cpu_ns)
