@@ -53,10 +53,10 @@ struct rt_options {
     int tier0_factor_x10 = 70;   // ... among those costing at least this multiple (x10) of the mean
     int resplit_samples = 0;     // a second ranking: samples [split, resplit) run with tiers ranked on `split` samples, the rest ranked on `resplit` (0 = off)
     int presplit_samples = 8;    // a first, shorter look: samples [presplit, split) already run with tiers ranked on it (0 = off)
-    int tier1_factor_x10 = 70;   // tier 1 = heavy pixels costing >= this/10 x the mean
-    int tier1_pixels = 256;      // heavy pixels served one per wave at a time (tier 1)
+    int tier1_factor_x10 = 45;   // tier 1 = heavy pixels costing >= this/10 x the mean
+    int tier1_pixels = 1536;     // heavy pixels served one per wave at a time (tier 1)
     int cost_smooth_percent = 0;  // ranking: a pixel's cost estimate is at least this share of its dearest 4-neighbour's (0 = own cost only)
-    int tier1_depth = 1;         // ... each wave taking about this many of them, one after the other
+    int tier1_depth = 3;         // ... each wave taking about this many of them, one after the other
     int heavy_factor_x10 = 20;   // a pixel is listed ("heavy") when its cost so far is >= this/10 x the mean ...
     int sparse_factor_x10 = 40;  // ... and goes to a sparse wave (tier 2) from this/10 x the mean; below, ordinary lanes take it first (tier 3)
     int heavy_max_tiles = 0;     // 0 = as many as the sparse workgroups hold at once
@@ -1012,11 +1012,12 @@ rt_status rt_debug_counters(rt_scene* s, unsigned long long* out16) {
     return RT_OK;
 }
 // Diagnostic builds: cycles the waves of the frame spent per part of the staged kernel's loop, summed over waves
-// ([0] box steps, [1] object tests, [2] stage C, [3] D, [4] E, [6] stage gating, [7] stage F + loop; s_memtime units).
-rt_status rt_debug_stage_cycles(rt_scene* s, unsigned long long* out8) {
-    if (!s || !out8) return invalid("null argument");
+// ([0] box steps, [1] object tests, [2] stage C, [3] D, [4] E, [6] stage gating, [7] stage F + loop; then, first wave of each
+// tier workgroup: [8] resolve + shade in the tier loops, [9] the whole tier loop; shader-clock cycles).
+rt_status rt_debug_stage_cycles(rt_scene* s, unsigned long long* out10) {
+    if (!s || !out10) return invalid("null argument");
     { const rt_status ud = use_device(s->device); if (ud != RT_OK) return ud; }
-    HIPCHK(hipMemcpy(out8, s->d_ray_counter + 17, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out10, s->d_ray_counter + 17, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 // Diagnostic builds: when the waves of the LAST launch ended, as two histograms of RT_DIAG_BINS bins of 1 ms after the first
@@ -1244,18 +1245,28 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         // queues empty leaves at once.
         const unsigned max_grid = (unsigned)(g_num_cu * per_cu_resident);
         auto rank_pixels = [&](rt_frame_params& q, dim3& grid_q) -> rt_status {
-            // Effective tier sizes.  Whether a whole workgroup per ray pays depends on how much idle hardware there is per
-            // heavy pixel, i.e. on the share of the frame this call renders (1/N in an N-GPU run): measured on rank-local
-            // renders of the headline frame (tools/partition_time.py, profiles/r01i_partition_times.log) the whole frame
-            // is best with no tier 0 (it is throughput-bound), half a frame with a moderate one, a quarter or less with
-            // every pixel above twice the mean on tier-0 workgroups.
+            // Effective tier sizes by the share of the frame this call renders (1/N in an N-GPU run): the fewer pixels a
+            // rank has per lane, the more of them can afford a wave of their own.  Measured on rank-local renders of the
+            // headline frame (tools/partition_time.py; profiles/r02_schedule_experiments.log, "tier 1 after the slot
+            // unions"): since trace_wave() skips the leaf slots a ray cannot meet, a wave per pixel (tier 1) beats a
+            // workgroup per pixel (tier 0, trace_group) at every share -- tier 0 stays available through the options.
             int e_tier0_pixels = g_opt.tier0_pixels, e_tier0_factor = g_opt.tier0_factor_x10, e_tier1_pixels = g_opt.tier1_pixels,
-                e_heavy_factor = g_opt.heavy_factor_x10, e_sparse_factor = g_opt.sparse_factor_x10, e_sparse_percent = g_opt.sparse_wg_percent;
+                e_tier1_factor = g_opt.tier1_factor_x10, e_tier1_depth = g_opt.tier1_depth, e_heavy_factor = g_opt.heavy_factor_x10,
+                e_sparse_factor = g_opt.sparse_factor_x10, e_sparse_percent = g_opt.sparse_wg_percent, e_work_percent = g_opt.sparse_work_percent;
             if (g_opt.tier0_auto) {
                 const double share = (double)n_pixels / ((double)f->nx * (double)f->ny);
-                if (share > 0.75) e_tier0_pixels = 0;
-                else if (share > 0.375) { e_tier0_pixels = 1024; e_tier0_factor = 40; e_tier1_pixels = 256; e_heavy_factor = 20; e_sparse_factor = 35; e_sparse_percent = 50; }
-                else { e_tier0_pixels = 4096; e_tier0_factor = 20; e_tier1_pixels = 0; e_heavy_factor = 20; e_sparse_factor = 20; e_sparse_percent = 80; }
+                e_tier0_pixels = 0;
+                if (tier0_possible) {          // trace_wave() is there (spheres-only scene resident in LDS)
+                    if (share > 0.75) { /* the whole frame: the defaults */ }
+                    else if (share > 0.375) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; }
+                    else if (share > 0.1875) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; e_work_percent = 20; }
+                    else { e_tier1_pixels = 8192; e_tier1_factor = 20; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 15; e_sparse_percent = 80; e_work_percent = 40; }
+                } else {                       // tier 1 is the 64-nodes-at-a-time walk there: only the very dearest pixels
+                    e_tier1_factor = 70; e_tier1_pixels = 256; e_tier1_depth = 1;
+                    if (share > 0.75) { }
+                    else if (share > 0.375) { e_heavy_factor = 20; e_sparse_factor = 35; e_sparse_percent = 50; }
+                    else { e_tier1_pixels = 0; e_heavy_factor = 20; e_sparse_factor = 20; e_sparse_percent = 80; }
+                }
             }
             rt_rank_params rp;
             memset(&rp, 0, sizeof(rp));
@@ -1267,12 +1278,12 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             rp.sparse_stride = (g_opt.sparse_stride > 0 && block.x >= 64) ? g_opt.sparse_stride : 0;
             rp.semi_stride = g_opt.semi_stride;
             rp.sparse_percent = e_sparse_percent;
-            rp.sparse_work_percent = g_opt.sparse_work_percent;
+            rp.sparse_work_percent = e_work_percent;
             rp.tier0_possible = tier0_possible ? 1 : 0;
-            rp.tier0_pixels = e_tier0_pixels; rp.tier1_pixels = e_tier1_pixels; rp.tier1_depth = g_opt.tier1_depth;
+            rp.tier0_pixels = e_tier0_pixels; rp.tier1_pixels = e_tier1_pixels; rp.tier1_depth = e_tier1_depth;
             rp.nx = f->nx; rp.smooth_percent = g_opt.cost_smooth_percent;
             if (e_sparse_factor < e_heavy_factor) e_sparse_factor = e_heavy_factor;
-            rp.heavy_factor = (float)e_heavy_factor / 10.0f; rp.sparse_factor = (float)e_sparse_factor / 10.0f; rp.tier1_factor = (float)g_opt.tier1_factor_x10 / 10.0f; rp.tier0_factor = (float)e_tier0_factor / 10.0f;
+            rp.heavy_factor = (float)e_heavy_factor / 10.0f; rp.sparse_factor = (float)e_sparse_factor / 10.0f; rp.tier1_factor = (float)e_tier1_factor / 10.0f; rp.tier0_factor = (float)e_tier0_factor / 10.0f;
             HIPCHK(rt_launch_rank(rp, stream));
             q.tile_order = s->d_tile_order; q.heavy_pixels = s->d_heavy_pixels; q.rank = s->d_rank;
             unsigned total = rp.normal_need + (rp.sparse_stride > 0 ? max_grid * (unsigned)e_sparse_percent / 100u : 0u);

@@ -851,17 +851,33 @@ DEV void wave_leaves_load(const SceneView& sc, const unsigned int* leaves, int n
         }
     }
 }
-DEV bool trace_wave(const SceneView& sc, const Ray& r, HitInfo& best, const WaveLeaves& w, int n_leaves) {
+// `ranges` (LDS, or null): per register slot k the union of the boxes of leaves 64 k .. 64 k + 63 (eight floats each: lo,
+// hi, padding) -- the leaves are in depth-first order, so a slot is a compact patch of the scene.  Lane k tests slot k's
+// union first and a slot whose union the ray misses is skipped: by the same monotonicity that carries the walk array
+//  none of its leaves' boxes could pass.
+DEV bool trace_wave(const SceneView& sc, const Ray& r, HitInfo& best, const WaveLeaves& w, int n_leaves, const float* ranges = nullptr) {
     const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     const float tmin = 0.001f;
     if (!inv_is_finite(inv)) return trace<true>(sc, r, best);   // wave-uniform
     const float a = dot(r.d, r.d);
     const int lane = (int)(threadIdx.x & 63u);
+    unsigned int slot_mask = 0xFFFFFFFFu;
+    if (ranges) {
+        bool meets = false;
+        if (lane < RT_WAVE_SLOTS) {
+            const float* q = ranges + lane * 8;
+            float t_enter, t_exit;
+            slab_interval(make_float4(q[0], q[1], q[2], 0.f), make_float4(q[3], q[4], q[5], 0.f), r.o, inv, tmin, t_enter, t_exit);
+            meets = !(t_exit <= t_enter);
+        }
+        slot_mask = (unsigned int)__ballot(meets);
+    }
     unsigned long long key = ~0ull;
     bool anomaly = false;
 #pragma unroll
     for (int k = 0; k < RT_WAVE_SLOTS; ++k) {
         if (k * 64 >= n_leaves) break;                           // wave-uniform
+        if (!((slot_mask >> k) & 1u)) continue;                  // wave-uniform: the ray misses this slot's union box
         const float4 lo4 = make_float4(w.lo[k][0], w.lo[k][1], w.lo[k][2], 0.f), hi4 = make_float4(w.hi[k][0], w.hi[k][1], w.hi[k][2], 0.f);
         float t_enter, t_exit;
         slab_interval(lo4, hi4, r.o, inv, tmin, t_enter, t_exit);

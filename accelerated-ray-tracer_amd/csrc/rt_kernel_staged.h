@@ -44,6 +44,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
 #ifdef RT_DIAG
     unsigned long long diag_local[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long diag_time[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long diag_shade_cycles = 0;
     unsigned long long diag_t_last = 0;
     const unsigned long long diag_t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz
     if ((threadIdx.x & 63) == 0) atomicMin(fp.ray_counter + RT_DIAG_T0_SLOT, diag_t_start);
@@ -102,6 +103,9 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     // with it the sequential chain that bounds the frame and every multi-GPU partition of it -- several times over.
     const bool tier0 = SPHERES_ONLY && LDS_MODE == 2 && (int)blockIdx.x < rk.tier0_wgs && fp.state_in != nullptr;   // workgroup-uniform
     const bool tier1 = sparse && !tier0 && (int)blockIdx.x < rk.tier0_wgs + rk.tier1_wgs && fp.state_in != nullptr;
+#ifdef RT_DIAG
+    const unsigned long long diag_t_start_cycles = __builtin_readcyclecounter();
+#endif
     if (tier0 || tier1) {
         __builtin_amdgcn_s_setprio(3);
         unsigned int* t0_scratch = reinterpret_cast<unsigned int*>(lds + fp.tier0_lds_offset);
@@ -122,6 +126,27 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                     base += __popcll(m);
                 }
                 if (threadIdx.x == 0) t0_scratch[0] = (unsigned int)base;
+                // trace_wave's slot unions (rt_device_funcs.h): box of leaves 64 k .. 64 k + 63, behind the leaf list where
+                // the scratch has room for them (it is sized for one entry per node; the interior nodes' entries are free)
+                const bool room = (n_nodes - base) * 4 >= RT_WAVE_SLOTS * 32 && base <= 64 * RT_WAVE_SLOTS;
+                if (threadIdx.x == 0) t0_scratch[2] = room ? 1u : 0u;
+                if (room) {
+                    float* ranges = reinterpret_cast<float*>(t0_leaves + base);
+                    for (int k = 0; k < RT_WAVE_SLOTS; ++k) {
+                        const int q = k * 64 + (int)threadIdx.x;
+                        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                        if (q < base) {
+                            const rt_node nd = sc.nodes[t0_leaves[q]];
+                            for (int a = 0; a < 3; ++a) { lo[a] = nd.bmin[a]; hi[a] = nd.bmax[a]; }
+                        }
+                        for (int a = 0; a < 3; ++a)
+                            for (int off = 32; off > 0; off >>= 1) {
+                                lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+                                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+                            }
+                        if (threadIdx.x == 0) { for (int a = 0; a < 3; ++a) { ranges[k * 8 + a] = lo[a]; ranges[k * 8 + 3 + a] = hi[a]; } ranges[k * 8 + 6] = 0.f; ranges[k * 8 + 7] = 0.f; }
+                    }
+                }
             }
             __syncthreads();
             t0_n_leaves = (int)t0_scratch[0];
@@ -173,6 +198,9 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                     f3 emitted, attenuation;
                     Ray scattered;
                     const bool go_on = shade<TEX>(sc, r, rec, pg, emitted, attenuation, scattered);
+#ifdef RT_DIAG
+                    if (threadIdx.x == 0) diag_shade_cycles += __builtin_readcyclecounter() - dg1;   // resolve + shade, tier loops
+#endif
 
                     rad = fma3(thr, emitted, rad);
                     if (!go_on) break;
@@ -201,9 +229,13 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
         else if (SPHERES_ONLY && tier1_wave) {
             WaveLeaves wl;
             wave_leaves_load(sc, t0_leaves, t0_n_leaves, wl);
-            tier_pixels([&](const Ray& r, HitInfo& h) { return trace_wave(sc, r, h, wl, t0_n_leaves); });
+            const float* slot_ranges = t0_scratch[2] ? reinterpret_cast<const float*>(t0_leaves + t0_n_leaves) : nullptr;   // workgroup-uniform
+            tier_pixels([&](const Ray& r, HitInfo& h) { return trace_wave(sc, r, h, wl, t0_n_leaves, slot_ranges); });
         } else tier_pixels([&](const Ray& r, HitInfo& h) { return trace_wide<SPHERES_ONLY>(sc, r, h); });
         __builtin_amdgcn_s_setprio(0);
+#ifdef RT_DIAG
+        if (threadIdx.x == 0) atomicAdd(fp.ray_counter + 26, (unsigned long long)(__builtin_readcyclecounter() - diag_t_start_cycles));   // whole tier loop of this wave
+#endif
         sparse = false;   // queue drained: this wave / workgroup becomes ordinary
     }
     // A sparse wave's few lanes are on the frame's critical path: let it win instruction-issue arbitration against the
@@ -574,6 +606,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     if ((threadIdx.x & 63) == 0) {
         for (int k = 0; k < 16; ++k) atomicAdd(fp.ray_counter + 1 + k, diag_local[k]);
         for (int k = 0; k < 8; ++k) atomicAdd(fp.ray_counter + 17 + k, diag_time[k]);
+        if (diag_shade_cycles) atomicAdd(fp.ray_counter + 25, diag_shade_cycles);
         const unsigned long long t0 = *reinterpret_cast<volatile unsigned long long*>(fp.ray_counter + RT_DIAG_T0_SLOT);
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
         unsigned long long bin = now > t0 ? (now - t0) / 100000ull : 0ull;   // 1 ms bins

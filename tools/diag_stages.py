@@ -30,9 +30,9 @@ print(f"  box lanes/step {c[2]/max(c[1],1):.1f}  leaf lanes/pass {c[4]/max(c[3],
 
 # cycles per part of the loop, summed over waves (diagnostic build only)
 if hasattr(L, "rt_debug_stage_cycles"):
-    t = np.zeros(8, np.uint64); L.rt_debug_stage_cycles.argtypes = [C.c_void_p, C.c_void_p]
+    t = np.zeros(10, np.uint64); L.rt_debug_stage_cycles.argtypes = [C.c_void_p, C.c_void_p]
     if L.rt_debug_stage_cycles(ds._p, t.ctypes.data) == 0:
-        t = [int(x) for x in t]; tot = max(sum(t), 1)
+        t = [int(x) for x in t][:8]; tot = max(sum(t), 1)
         labels = ["box steps", "object tests", "stage C", "stage D", "stage E", "-", "stage gating", "stage F + loop"]
         print("  wave cycles by part of the loop: " + "  ".join(f"{l} {100.0 * v / tot:.1f} %" for l, v in zip(labels, t) if l != "-"))
         print(f"  cycles per wave-ray(64): {tot / (rays / 64):.0f}")

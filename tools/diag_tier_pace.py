@@ -14,3 +14,8 @@ fb, st = ds.render(hs.frame(ns=500))
 c = np.zeros(16, np.uint64); L = art.rt_lib(); L.rt_debug_counters.argtypes = [C.c_void_p, C.c_void_p]; L.rt_debug_counters(ds._p, c.ctypes.data)
 c = [int(x) for x in c]
 print(sys.argv[1:], "frame %.1f ms (diag build)" % st.ms_render, "tier rays timed", c[15], "traversal cycles per ray %.0f" % (c[14] / max(c[15], 1)))
+
+if hasattr(L, "rt_debug_stage_cycles"):
+    t = np.zeros(10, np.uint64); L.rt_debug_stage_cycles.argtypes = [C.c_void_p, C.c_void_p]
+    if L.rt_debug_stage_cycles(ds._p, t.ctypes.data) == 0:
+        print("   tier loops, first wave of each tier workgroup: resolve + shade %.0f cycles per ray, whole loop %.0f cycles per ray (traversal %.0f)" % (int(t[8]) / max(c[15], 1), int(t[9]) / max(c[15], 1), c[14] / max(c[15], 1)))
