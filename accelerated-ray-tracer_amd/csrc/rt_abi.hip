@@ -1257,9 +1257,12 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
                 const double share = (double)n_pixels / ((double)f->nx * (double)f->ny);
                 e_tier0_pixels = 0;
                 if (tier0_possible) {          // trace_wave() is there (spheres-only scene resident in LDS)
-                    if (share > 0.75) { /* the whole frame: the defaults */ }
-                    else if (share > 0.375) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; }
-                    else if (share > 0.1875) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; e_work_percent = 20; }
+                    // keyed by pixels per resident lane (the 1200x800 frame: 3.7 whole, 1.8 / 0.9 / 0.5 for a half, a quarter,
+                    // an eighth; a quarter of 1920x1080 is 2.0): what matters is how empty the machine is, not the fraction
+                    const double per_lane = (double)n_pixels / ((double)max_grid * (double)block.x);
+                    if (per_lane > 2.75) { /* the defaults */ }
+                    else if (per_lane > 1.375) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; }
+                    else if (per_lane > 0.6875) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; e_work_percent = 20; }
                     else { e_tier1_pixels = 8192; e_tier1_factor = 20; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 15; e_sparse_percent = 80; e_work_percent = 40; }
                 } else {                       // tier 1 is the 64-nodes-at-a-time walk there: only the very dearest pixels
                     e_tier1_factor = 70; e_tier1_pixels = 256; e_tier1_depth = 1;
