@@ -67,8 +67,8 @@ def test_bench_configuration_matches_oracle(gpu, orc):
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_rank_shares_of_the_bench_frame(gpu, orc, world):
-    """Each rank's share of the 1200x800 @ 500 frame in a 2-, 4- and 8-GPU run (full-size frame, so every tier of the
-    schedule is populated), default options: assembled frame == oracle on the bands, total rays == whole-frame rays."""
+    """Each rank's share of the 1200x800 @ 500 frame in a 2-, 4- and 8-GPU run (full-size frame, so the tiers the default
+    sizing uses -- 1, 2, 3 -- are populated; tier 0 is covered by the hand-set cases of test_gpu_parity.py), default options: assembled frame == oracle on the bands, total rays == whole-frame rays."""
     nx, ny, ns = 1200, 800, 500
     hs = gpu.HostScene("random_scene", nx, ny)
     ds = gpu.DeviceScene(hs)
