@@ -72,7 +72,8 @@ MATERIAL_DTYPE = np.dtype([("kind", "<i4"), ("tex", "<i4"), ("fuzz", "<f4"), ("i
 RT_ABI_SYMBOLS = ["rt_init", "rt_shutdown", "rt_strerror", "rt_last_hip_error", "rt_last_error_detail", "rt_scene_create",
                   "rt_scene_destroy", "rt_frame_local_rows", "rt_local_to_global_row", "rt_render", "rt_frame_finish",
                   "rt_set_option", "rt_reset_options", "rt_scene_walk_info", "rt_init_devices", "rt_multi_create", "rt_multi_render",
-                  "rt_multi_destroy", "rt_multi_device_count", "rt_multi_row_owner", "rt_plan_walk_array", "rt_regroup_leaves"]
+                  "rt_multi_destroy", "rt_multi_device_count", "rt_multi_row_owner", "rt_multi_probe_rccl", "rt_multi_debug_uninterleave",
+                  "rt_plan_walk_array", "rt_regroup_leaves"]
 
 _rt = None
 _host = None
@@ -135,6 +136,8 @@ def rt_lib():
         L.rt_multi_destroy.argtypes = [C.c_void_p]
         L.rt_multi_device_count.argtypes = [C.c_void_p]
         L.rt_multi_row_owner.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.rt_multi_probe_rccl.argtypes = [C.c_char_p]
+        L.rt_multi_debug_uninterleave.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         L.rt_plan_walk_array.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rt_regroup_leaves.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]

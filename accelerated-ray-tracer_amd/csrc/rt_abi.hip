@@ -1,6 +1,8 @@
 // rt_abi.hip -- implementation of include/rt_abi.h: device bookkeeping, scene
-// validation + upload, frame launch, statistics.  The kernels are in
-// rt_device.hip.  There is no CPU render path here or anywhere else in the
+// validation + upload, the walk-array planner, tier data and cost prior, frame
+// launch, statistics.  The kernels are in rt_kernel_pixel.hip, rt_staged_*.hip
+// (rt_kernel_staged.h), rt_tier_*.hip (rt_kernel_tier.h) and rt_rank.hip.
+// There is no CPU render path here or anywhere else in the
 // library: without a HIP device every entry point fails with
 // RT_ERR_NO_DEVICE / RT_ERR_HIP.
 #include <hip/hip_runtime.h>
@@ -48,9 +50,9 @@ struct rt_options {
     int newpath_threshold = 0;   // lanes waiting for a new path before stage E runs; 0 = by kernel family: 24 spheres-only, 8 general (measured: Book-2 final 382 -> 364 ms with 8, Book-1 32.2 -> 35.1)
     int sparse_stride = 8;      // lanes per pixel in sparse waves (64 / live lanes); 0 disables sparse waves
     int split_samples = 32;      // samples per pixel rendered before pixels are ranked by measured cost
-    int tier0_auto = 1;          // size the tiers from the share of the frame this call renders (see rank_pixels); 0 = the knobs as set
-    int tier0_pixels = 128;      // dearest pixels served one per WORKGROUP (tier 0, spheres-only scenes); 0 = off
-    int tier0_factor_x10 = 70;   // ... among those costing at least this multiple (x10) of the mean
+    int tier_auto = 1;           // size the tiers from the share of the frame this call renders (see rank_pixels); 0 = the knobs as set
+    int tier_kernel = 1;         // tier 1 of the list goes to the tier kernel (rt_kernel_tier.h) on a side stream; 0 = no tier 1
+    int prior = 1;               // the first part of a split frame is already ranked: on the cost prior of the calibration frame
     int resplit_samples = 0;     // a second ranking: samples [split, resplit) run with tiers ranked on `split` samples, the rest ranked on `resplit` (0 = off)
     int presplit_samples = 8;    // a first, shorter look: samples [presplit, split) already run with tiers ranked on it (0 = off)
     int tier1_factor_x10 = 45;   // tier 1 = heavy pixels costing >= this/10 x the mean
@@ -71,10 +73,6 @@ struct rt_options {
     int scan_nodes = 24;         // scenes whose walk array has at most this many nodes are scanned in lockstep (lds_mode 4); 0 = never
     int multi_force_rccl = 0;    // rt_multi_render: go through the RCCL gather even with one device (tests the path on a one-GPU box)
     int lpt = 1;                 // cost prepass + longest-first tile order (staged kernel, ns >= 2 * split_samples)
-    int wf_slots = 0;            // 0 = as many as fit in LDS (<= 1024)
-    int wf_pause_lanes = 32;
-    int wf_threads = 512;
-    int wf_wg_per_cu = 1;
 };
 rt_options g_opt;
 
@@ -133,6 +131,10 @@ struct rt_scene {
     unsigned int* d_heavy_pixels = nullptr;       // heavy pixels, dearest first
     size_t tile_capacity = 0, pixel_capacity = 0;
     rt_rank_info* d_rank = nullptr;               // tier sizes of the next ranked launch (written and read on the device only)
+    unsigned int* d_cal_cost = nullptr;           // cost prior: rays per pixel of the calibration frame (cal_nx x cal_ny at 4 spp)
+    int cal_nx = 0, cal_ny = 0;
+    hipStream_t tier_stream = nullptr;            // the tier kernel's stream (forked from / joined to the caller's stream by events)
+    hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ranked_frame = false;                    // the pending frame used the cost-aware schedule
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool frame_pending = false;
@@ -145,7 +147,6 @@ namespace {
 // picks the kernel family; LDS_MODE and texture level select the instantiation inside (rt_staged_*.hip)
 hipError_t launch_render(int kernel, int lds_mode, const rt_scene* s, const rt_frame_params& fp, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream) {
     if (kernel == RT_KERNEL_PIXEL) return rt_launch_pixel(s->spheres_only, s->tex_level, s->need_uv, s->dev, fp, grid, block, stream);
-    if (kernel == RT_KERNEL_WAVEFRONT) return rt_launch_wavefront(lds_mode, s->tex_level, s->dev, fp, grid, block, lds_bytes, stream);
     if (s->spheres_only) {
         if (s->tex_level <= 1) return rt_launch_staged_spheres(s->tex_level, lds_mode, s->dev, fp, grid, block, lds_bytes, stream);
         return rt_launch_staged_spheres_tex(lds_mode, s->dev, fp, grid, block, lds_bytes, stream);
@@ -582,7 +583,7 @@ const char* rt_last_error_detail(void) { return g_detail.c_str(); }
 rt_status rt_set_option(const char* key, int value) {
     if (!key) return invalid("null option key");
     const std::string k(key);
-    if (k == "kernel") { if (value != RT_KERNEL_PIXEL && value != RT_KERNEL_STAGED && value != RT_KERNEL_WAVEFRONT) return invalid("kernel: 0 (pixel), 3 (staged) or 4 (wavefront)"); g_opt.kernel = value; }
+    if (k == "kernel") { if (value != RT_KERNEL_PIXEL && value != RT_KERNEL_STAGED) return invalid("kernel: 0 (pixel) or 3 (staged)"); g_opt.kernel = value; }
     else if (k == "leaf_threshold") { if (value < 1 || value > 64) return invalid("leaf_threshold: 1..64"); g_opt.leaf_threshold = value; }
     else if (k == "box_threshold") { if (value < 1 || value > 64) return invalid("box_threshold: 1..64"); g_opt.box_threshold = value; }
     else if (k == "medium_threshold") { if (value < 1 || value > 64) return invalid("medium_threshold: 1..64"); g_opt.medium_threshold = value; }
@@ -591,9 +592,9 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "sparse_stride") { if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return invalid("sparse_stride: 0, 2, 4, ... 64"); g_opt.sparse_stride = value; }
     else if (k == "sparse_factor_x10") { if (value < 10 || value > 1000) return invalid("sparse_factor_x10: 10..1000"); g_opt.sparse_factor_x10 = value; }
     else if (k == "heavy_factor_x10") { if (value < 10 || value > 1000) return invalid("heavy_factor_x10: 10..1000"); g_opt.heavy_factor_x10 = value; }
-    else if (k == "tier0_auto") { if (value < 0 || value > 1) return invalid("tier0_auto: 0 or 1"); g_opt.tier0_auto = value; }
-    else if (k == "tier0_pixels") { if (value < 0 || value > 4096) return invalid("tier0_pixels: 0..4096"); g_opt.tier0_pixels = value; }
-    else if (k == "tier0_factor_x10") { if (value < 10 || value > 10000) return invalid("tier0_factor_x10: 10..10000"); g_opt.tier0_factor_x10 = value; }
+    else if (k == "tier_auto") { if (value < 0 || value > 1) return invalid("tier_auto: 0 or 1"); g_opt.tier_auto = value; }
+    else if (k == "tier_kernel") { if (value < 0 || value > 1) return invalid("tier_kernel: 0 or 1"); g_opt.tier_kernel = value; }
+    else if (k == "prior") { if (value < 0 || value > 1) return invalid("prior: 0 or 1"); g_opt.prior = value; }
     else if (k == "presplit_samples") { if (value < 0 || value > 4096) return invalid("presplit_samples: 0..4096"); g_opt.presplit_samples = value; }
     else if (k == "resplit_samples") { if (value < 0 || value > 65536) return invalid("resplit_samples: 0..65536"); g_opt.resplit_samples = value; }
     else if (k == "split_samples") { if (value < 1 || value > 4096) return invalid("split_samples: 1..4096"); g_opt.split_samples = value; }
@@ -611,10 +612,6 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "scan_nodes") { if (value < 0 || value > 64) return invalid("scan_nodes: 0..64"); g_opt.scan_nodes = value; }
     else if (k == "multi_force_rccl") { if (value < 0 || value > 1) return invalid("multi_force_rccl: 0 or 1"); g_opt.multi_force_rccl = value; }
     else if (k == "lpt") { if (value < 0 || value > 1) return invalid("lpt: 0 or 1"); g_opt.lpt = value; }
-    else if (k == "wf_slots") { if (value < 0 || value > 4096 || (value % 64)) return invalid("wf_slots: 0 or a multiple of 64 up to 4096"); g_opt.wf_slots = value; }
-    else if (k == "wf_threads") { if (value != 256 && value != 512 && value != 768 && value != 1024) return invalid("wf_threads: 256, 512, 768 or 1024"); g_opt.wf_threads = value; }
-    else if (k == "wf_wg_per_cu") { if (value < 1 || value > 8) return invalid("wf_wg_per_cu: 1..8"); g_opt.wf_wg_per_cu = value; }
-    else if (k == "wf_pause_lanes") { if (value < 1 || value > 64) return invalid("wf_pause_lanes: 1..64"); g_opt.wf_pause_lanes = value; }
     else if (k == "threads") { if (value != 0 && (value < 64 || value > 768 || (value % 64))) return invalid("threads: 0 (per kernel family) or a multiple of 64 up to 768 (512 for the lean spheres-only kernels)"); g_opt.threads = value; }
     else if (k == "lds_mode") { if (value < -1 || value > 4) return invalid("lds_mode: -1..4"); g_opt.lds_mode = value; }
     else if (k == "steps_per_trip") { if (value < 1 || value > 64) return invalid("steps_per_trip: 1..64"); g_opt.steps_per_trip = value; }
@@ -637,6 +634,9 @@ rt_status rt_scene_destroy(rt_scene* s) {
     if (s->d_heavy_list) (void)hipFree(s->d_heavy_list);
     if (s->d_heavy_pixels) (void)hipFree(s->d_heavy_pixels);
     if (s->d_rank) (void)hipFree(s->d_rank);
+    if (s->d_cal_cost) (void)hipFree(s->d_cal_cost);
+    if (s->tier_stream) (void)hipStreamDestroy(s->tier_stream);
+    for (int k = 0; k < 4; ++k) { if (s->ev_fork[k]) (void)hipEventDestroy(s->ev_fork[k]); if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]); }
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
     delete s;
@@ -645,7 +645,8 @@ rt_status rt_scene_destroy(rt_scene* s) {
 
 namespace {
 // Pass counts of the reference's nodes on a small frame through the scene's own camera (kernel 0 with its counters on).
-rt_status measure_pass_counts(rt_scene* s, const rt_node* d_tree, int n_tree, std::vector<double>& pass, double& rays, std::vector<float>* sample = nullptr, uint32_t sample_stride = 0) {
+// keep_cost: the pass's per-pixel ray counts stay in the scene as the cost prior of ranked first parts (rt_prior_kernel)
+rt_status measure_pass_counts(rt_scene* s, const rt_node* d_tree, int n_tree, std::vector<double>& pass, double& rays, std::vector<float>* sample = nullptr, uint32_t sample_stride = 0, bool keep_cost = false) {
     const rt_camera& c = s->dev.camera;
     const double hw = sqrt((double)c.horizontal[0] * c.horizontal[0] + (double)c.horizontal[1] * c.horizontal[1] + (double)c.horizontal[2] * c.horizontal[2]);
     const double vh = sqrt((double)c.vertical[0] * c.vertical[0] + (double)c.vertical[1] * c.vertical[1] + (double)c.vertical[2] * c.vertical[2]);
@@ -658,13 +659,15 @@ rt_status measure_pass_counts(rt_scene* s, const rt_node* d_tree, int n_tree, st
     rt_scene_dev dev = s->dev;
     dev.nodes_ref = d_tree; dev.n_nodes_ref = n_tree;          // the tree kernel 0 walks in this pass
     unsigned int* d_pass = nullptr;
+    unsigned int* d_cost = nullptr;
     float* d_fb = nullptr;
     HIPCHK(hipMalloc((void**)&d_pass, (size_t)n * sizeof(unsigned int)));
     hipError_t e = hipMalloc((void**)&d_fb, (size_t)nx * ny * 3 * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(d_pass); HIPCHK(e); }
+    if (keep_cost && hipMalloc((void**)&d_cost, (size_t)nx * ny * sizeof(unsigned int)) != hipSuccess) d_cost = nullptr;   // no prior then
     rt_frame_params fp;
     memset(&fp, 0, sizeof(fp));
-    fp.fb = d_fb; fp.ray_counter = s->d_ray_counter; fp.work_counter = s->d_work_counter; fp.node_pass = d_pass;
+    fp.fb = d_fb; fp.ray_counter = s->d_ray_counter; fp.work_counter = s->d_work_counter; fp.node_pass = d_pass; fp.pixel_cost = d_cost;
     fp.node_pass_lds = (size_t)n * sizeof(unsigned int) <= 48u * 1024u ? 1 : 0;
     fp.seed_base = 1984; fp.nx = nx; fp.ny = ny; fp.ns = 4; fp.gamma = 1.0f;
     fp.tile_rows = ny; fp.tile_first = 0; fp.tile_stride = 1; fp.local_rows = ny;
@@ -700,6 +703,10 @@ rt_status measure_pass_counts(rt_scene* s, const rt_node* d_tree, int n_tree, st
     } while (0);
     (void)hipFree(d_pass); (void)hipFree(d_fb);
     if (d_sample) (void)hipFree(d_sample);
+    if (d_cost) {
+        if (e == hipSuccess) { if (s->d_cal_cost) (void)hipFree(s->d_cal_cost); s->d_cal_cost = d_cost; s->cal_nx = nx; s->cal_ny = ny; }
+        else (void)hipFree(d_cost);
+    }
     if (e != hipSuccess) { g_last_hip_error = (int)e; g_detail = std::string("calibration pass: ") + hipGetErrorString(e); st = RT_ERR_HIP; }
     pass.assign((size_t)n, 0.0);
     for (int i = 0; i < n; ++i) pass[i] = (double)h[i];
@@ -716,6 +723,58 @@ void device_nodes(const rt_node* nodes, size_t n, std::vector<rt_node>& out) {
     }
 }
 
+// Tier data (rt_kernel_tier.h): the scene's leaves -- the reference's single-object nodes, in its depth-first order, which
+// every walk array keeps -- as two float4 arrays padded to whole 64-leaf slots, and per slot the union of its boxes.  A scene
+// with more than 64 slots (one lane tests one slot's union) or more than two constant_medium leaves gets none: it renders
+// without a tier kernel.
+rt_status build_tier_data(rt_scene* s, const rt_scene_desc* d) {
+    s->dev.leaf_lo = s->dev.leaf_hi = nullptr; s->dev.slot_ranges = nullptr;
+    s->dev.n_leaves = s->dev.n_slots = s->dev.n_media_leaves = 0;
+    s->dev.media_ord[0] = s->dev.media_ord[1] = 0x7FFFFFFF;
+    std::vector<const rt_node*> leaves;
+    for (int i = 0; i < d->n_nodes; ++i) if (d->nodes[i].prim >= 0) leaves.push_back(&d->nodes[i]);
+    const int m = (int)leaves.size();
+    if (m == 0 || m > 64 * 64) return RT_OK;
+    int media = 0, media_ord[2] = {0x7FFFFFFF, 0x7FFFFFFF};
+    for (int q = 0; q < m; ++q)
+        if (RT_PRIM_KIND(leaves[q]->prim) == RT_PRIM_MEDIUM) { if (media < 2) media_ord[media] = q; ++media; }
+    if (media > 2) return RT_OK;
+    const int slots = (m + 63) / 64;
+    std::vector<float> lo((size_t)slots * 64 * 4), hi((size_t)slots * 64 * 4), ranges((size_t)slots * 8, 0.0f);
+    for (int k = 0; k < slots; ++k) {
+        float rl[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, rh[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int l = 0; l < 64; ++l) {
+            const int q = k * 64 + l;
+            float* a = &lo[(size_t)q * 4];
+            float* b = &hi[(size_t)q * 4];
+            int32_t prim = -1;
+            if (q < m) {
+                for (int c = 0; c < 3; ++c) { a[c] = leaves[q]->bmin[c]; b[c] = leaves[q]->bmax[c]; rl[c] = fminf(rl[c], a[c]); rh[c] = fmaxf(rh[c], b[c]); }
+                prim = leaves[q]->prim;
+            } else {
+                for (int c = 0; c < 3; ++c) { a[c] = 0.0f; b[c] = 0.0f; }
+            }
+            memcpy(&a[3], &prim, 4);
+            b[3] = 0.0f;
+        }
+        for (int c = 0; c < 3; ++c) { ranges[(size_t)k * 8 + c] = rl[c]; ranges[(size_t)k * 8 + 3 + c] = rh[c]; }
+    }
+    const float* d_lo = nullptr; const float* d_hi = nullptr; const float* d_ranges = nullptr;
+    rt_status st = upload(lo.data(), lo.size(), &d_lo);
+    if (st != RT_OK) return st;
+    s->allocs.push_back(const_cast<float*>(d_lo));
+    st = upload(hi.data(), hi.size(), &d_hi);
+    if (st != RT_OK) return st;
+    s->allocs.push_back(const_cast<float*>(d_hi));
+    st = upload(ranges.data(), ranges.size(), &d_ranges);
+    if (st != RT_OK) return st;
+    s->allocs.push_back(const_cast<float*>(d_ranges));
+    s->dev.leaf_lo = reinterpret_cast<const float4*>(d_lo); s->dev.leaf_hi = reinterpret_cast<const float4*>(d_hi); s->dev.slot_ranges = d_ranges;
+    s->dev.n_leaves = m; s->dev.n_slots = slots; s->dev.n_media_leaves = media;
+    s->dev.media_ord[0] = media_ord[0]; s->dev.media_ord[1] = media_ord[1];
+    return RT_OK;
+}
+
 // builds the walk array (see "Collapse" above) and points dev.nodes at it
 rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
     const int n = d->n_nodes;
@@ -725,7 +784,7 @@ rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
     std::vector<float> ray_sample;
     double root_visits = 0.0;
     if (g_opt.bvh_collapse >= 2) {
-        const rt_status st = measure_pass_counts(s, s->dev.nodes_ref, n, pass, root_visits);
+        const rt_status st = measure_pass_counts(s, s->dev.nodes_ref, n, pass, root_visits, nullptr, 0, /*keep_cost=*/true);
         if (st != RT_OK) return st;
     }
     const bool measured = root_visits > 0.0;
@@ -910,6 +969,18 @@ rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_sce
         rt_scene_destroy(s);
         return RT_ERR_HIP;
     }
+    {   // the tier kernel's stream and the events that fork it from / join it to the caller's stream, one pair per ranked part
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        e = hipStreamCreateWithPriority(&s->tier_stream, hipStreamNonBlocking, prio_hi);
+        for (int k = 0; k < 4 && e == hipSuccess; ++k) {
+            e = hipEventCreateWithFlags(&s->ev_fork[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join[k], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) { g_last_hip_error = (int)e; g_detail = "creating the tier stream failed"; rt_scene_destroy(s); return RT_ERR_HIP; }
+    }
+    st = build_tier_data(s, d);
+    if (st != RT_OK) { rt_scene_destroy(s); return st; }
     st = build_walk(s, d);
     if (st != RT_OK) { rt_scene_destroy(s); return st; }
     s->node_bytes = (size_t)s->dev.n_nodes * sizeof(rt_node);
@@ -988,10 +1059,8 @@ rt_status rt_frame_finish(rt_scene* s, rt_stats* stats) {
     HIPCHK(hipEventSynchronize(s->ev_stop));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
-    unsigned long long rays = 0, err_flag = 0;
+    unsigned long long rays = 0;
     HIPCHK(hipMemcpy(&rays, s->d_ray_counter, sizeof(rays), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&err_flag, s->d_ray_counter + 31, sizeof(err_flag), hipMemcpyDeviceToHost));
-    if (err_flag) { s->frame_pending = false; g_detail = "render kernel hit its iteration cap (scheduler bug); frame is incomplete"; return RT_ERR_HIP; }
     s->pending_stats.ms_render = (double)ms;
     s->pending_stats.rays = rays;
     if (s->ranked_frame && s->d_rank) {   // how many pixels the last ranking listed as heavy (diagnostics)
@@ -1092,12 +1161,12 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     // spheres-only kernels, 3 otherwise: see the workgroup shapes below), else once (one big workgroup per CU), else nodes only
     int lds_mode = g_opt.lds_mode;
     const bool lean_family = s->spheres_only && s->tex_level < 2;
-    const int want_per_cu = g_opt.wg_per_cu > 0 ? g_opt.wg_per_cu : (lean_family ? 2 : 3);
-    const size_t budget2 = g_lds_per_cu / (size_t)want_per_cu - 1024, budget1 = g_lds_per_cu - 2048;
+    const size_t budget1 = g_lds_per_cu - 2048;   // one workgroup per CU
     if (lds_mode < 0) {
+        // nodes + spheres where they fit a CU at all (several workgroups each with its own image, or one big workgroup
+        // sharing one: see the workgroup shapes below), else nodes only, else everything through L1 / L2
         // (lds_mode 3 -- materials and textures in LDS too -- is selectable but measured no faster: profiles/r01_sweep34)
-        if (s->node_bytes + s->sphere_bytes <= budget2) lds_mode = 2;
-        else if (s->node_bytes + s->sphere_bytes <= budget1) lds_mode = 2;
+        if (s->node_bytes + s->sphere_bytes <= budget1) lds_mode = 2;
         else if (s->node_bytes <= budget1) lds_mode = 1;
         else lds_mode = 0;
     }
@@ -1109,68 +1178,18 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     if (lds_mode >= 2 && lds_mode <= 3) lds_bytes += s->sphere_bytes;
     if (lds_mode == 3) lds_bytes += s->shade_bytes;
     if (lds_bytes > budget1) return invalid("requested lds_mode does not fit the CU's LDS");
-
-    // the wavefront kernel covers spheres-only scenes with inline/solid/checker textures and frames whose
-    // pixel coordinates pack into 16 bits each; everything else runs the staged kernel
-    int kernel = g_opt.kernel;
-    if (kernel == RT_KERNEL_WAVEFRONT && !(s->spheres_only && s->tex_level <= 1 && f->nx <= 65535 && local_rows <= 65535)) kernel = RT_KERNEL_STAGED;
-    int wf_slots = 0;
-    if (kernel == RT_KERNEL_WAVEFRONT) {
-        const int threads = g_opt.wf_threads;
-        const size_t cap = g_lds_per_cu / (size_t)g_opt.wf_wg_per_cu - 1024;
-        // prefer nodes + spheres in LDS; drop spheres to L1/L2 if that is what it takes to get >= 1.5 slots per lane
-        for (int attempt = 0; attempt < 2 && wf_slots == 0; ++attempt) {
-            size_t scene = 0;
-            if (lds_mode >= 1) scene += s->node_bytes;
-            if (lds_mode >= 2) scene += s->sphere_bytes;
-            scene = (scene + 15) & ~(size_t)15;
-            long fit = scene + 256 < cap ? (long)((cap - scene - 256) / RT_WF_BYTES_PER_SLOT) : 0;
-            fit = fit / 64 * 64;
-            if (fit > 2048) fit = 2048;
-            if (g_opt.wf_slots) { if (g_opt.wf_slots <= fit) fit = g_opt.wf_slots; else fit = 0; }
-            if (fit >= threads + threads / 4 || (attempt == 1 && fit >= threads)) { wf_slots = (int)fit; lds_bytes = scene + (size_t)fit * RT_WF_BYTES_PER_SLOT + 256; }
-            else if (lds_mode == 2) lds_mode = 1;
-            else break;
-        }
-        if (wf_slots == 0) { kernel = RT_KERNEL_STAGED; lds_mode = g_opt.lds_mode; }
-    }
-    if (kernel != g_opt.kernel && kernel == RT_KERNEL_STAGED && g_opt.kernel == RT_KERNEL_WAVEFRONT) {
-        // recompute the plain LDS plan for the fallback
-        lds_mode = g_opt.lds_mode;
-        if (lds_mode < 0) {
-            if (s->node_bytes + s->sphere_bytes <= budget2) lds_mode = 2;
-            else if (s->node_bytes <= budget2) lds_mode = 1;
-            else if (s->node_bytes + s->sphere_bytes <= budget1) lds_mode = 2;
-            else if (s->node_bytes <= budget1) lds_mode = 1;
-            else lds_mode = 0;
-        }
-        lds_bytes = 0;
-        if (lds_mode >= 1) lds_bytes += s->node_bytes;
-        if (lds_mode >= 2) lds_bytes += s->sphere_bytes;
-    }
-    fp.wf_slots = wf_slots;
-    fp.wf_pause_lanes = g_opt.wf_pause_lanes;
-    {   // generous bound: every live slot retires a ray segment (or a paused walk advances) each iteration
-        const double segs = (double)local_rows * f->nx * (double)f->ns * 51.0;
-        const double per_wg = segs / (wf_slots > 0 ? wf_slots : 1) * 4.0 + 100000.0;
-        fp.wf_max_iterations = per_wg > 4.0e9 ? 4000000000u : (uint32_t)per_wg;
-    }
+    const int kernel = g_opt.kernel;
 
     dim3 grid, block;
     int per_cu_resident = 1;   // workgroups of this launch that can be resident on one CU (persistent kernels)
-    if (kernel == RT_KERNEL_WAVEFRONT) {
-        block = dim3(g_opt.wf_threads);
-        const unsigned need = (fp.work_items + (unsigned)wf_slots - 1) / (unsigned)wf_slots;
-        const unsigned want = (unsigned)(g_num_cu * g_opt.wf_wg_per_cu);
-        grid = dim3(want < need ? want : need);
-    } else if (kernel == RT_KERNEL_PIXEL) {
+    if (kernel == RT_KERNEL_PIXEL) {
         block = dim3(256);
         grid = dim3((fp.work_items + 255u) / 256u);
     } else {
         // workgroup shape per kernel family (register budgets: launch bounds, rt_device.h): the lean spheres-only
         // kernels 2 x 512 threads per CU (4 waves per SIMD), the others 3 x 256 (3 waves per SIMD; workgroups of four
         // waves, one per SIMD -- 2 x 384 threads is the same occupancy and measured 1.4x slower on the Cornell box)
-        const bool lean = s->spheres_only && s->tex_level < 2;
+        const bool lean = lean_family;
         const int fam_max_threads = lean ? RT_LEAN_MAX_THREADS : RT_HEAVY_MAX_THREADS;
         const int lds_fit = lds_bytes ? (int)(g_lds_per_cu / (lds_bytes + 512)) : 8;
         int per_cu = g_opt.wg_per_cu > 0 ? g_opt.wg_per_cu : (lean ? 2 : 3);
@@ -1188,43 +1207,83 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         grid = dim3(want < need ? want : need);
         per_cu_resident = per_cu;
     }
-    // tier 0 of the cost-aware schedule (spheres-only scenes resident in LDS): per-workgroup scratch behind the scene
-    // data -- header (16 B), 2 x 16 reduction slots (256 B), the leaf list (4 B per node: at most that many leaves)
-    fp.tier0_lds_offset = 0;
-    bool tier0_possible = false;
-    if (kernel == RT_KERNEL_STAGED && s->spheres_only && lds_mode == 2 && block.x >= 64 && block.x <= 1024) {
-        const size_t scratch = ((size_t)16 + 256 + (size_t)s->dev.n_nodes * 4 + 255) & ~(size_t)255;
-        if (lds_bytes + scratch + 512 <= g_lds_per_cu / (size_t)per_cu_resident) {
-            fp.tier0_lds_offset = (uint32_t)lds_bytes;
-            lds_bytes += scratch;
-            tier0_possible = true;
+    // ---- the tier kernel of ranked launches (rt_kernel_tier.h): its LDS image and where its workgroups find room.
+    // Lean family: the main kernel's 4 x 96 registers per SIMD leave 128 free, so ONE tier workgroup (four waves, one per
+    // SIMD, <= 128 VGPRs) is resident on a CU beside a full main grid if the LDS left over holds its image.  Other families:
+    // no register room beside a full main grid; the ranking makes main workgroups leave (main_skip_wgs) and a tier workgroup
+    // has what one of them had.  The image always holds the leaf arrays; spheres, then materials + textures, where they fit.
+    bool tier_possible = false;
+    size_t tier_lds = 0;
+    unsigned tier_grid = 0;
+    int tier_waves_per_main_wg = 0;
+    fp.tier_lds_spheres = fp.tier_lds_materials = 0;
+    if (kernel == RT_KERNEL_STAGED && g_opt.tier_kernel && s->dev.leaf_lo != nullptr && g_opt.tier1_pixels > 0) {
+        size_t budget;
+        if (lean_family) {
+            const size_t used = (size_t)per_cu_resident * (lds_bytes + 512);
+            budget = g_lds_per_cu > used + 1024 ? g_lds_per_cu - used - 1024 : 0;
+        } else {
+            budget = g_lds_per_cu / (size_t)per_cu_resident - 1024;                  // the slot of one main workgroup ...
+            const size_t per_tier_wg = budget / (block.x / RT_TIER_THREADS > 0 ? block.x / RT_TIER_THREADS : 1);
+            budget = per_tier_wg;                                                    // ... shared by the tier workgroups it holds
+            tier_waves_per_main_wg = (int)(block.x / 64u);
+        }
+        const int ns_ = s->dev.n_slots, nsph = s->dev.n_spheres, nm = s->dev.n_materials, nt = s->dev.n_textures;
+        if (rt_tier_lds_bytes(ns_, nsph, false, nm, nt, false) <= budget) {
+            tier_possible = true;
+            if (rt_tier_lds_bytes(ns_, nsph, true, nm, nt, false) <= budget) fp.tier_lds_spheres = 1;
+            if (rt_tier_lds_bytes(ns_, nsph, fp.tier_lds_spheres != 0, nm, nt, true) <= budget) fp.tier_lds_materials = 1;
+            tier_lds = rt_tier_lds_bytes(ns_, nsph, fp.tier_lds_spheres != 0, nm, nt, fp.tier_lds_materials != 0);
+            // the tier kernel's grid is fixed before the ranking has sized the tier: what can be resident beside the main
+            // grid (one workgroup per CU) and as much again queued behind it; workgroups beyond the tier's size leave at once
+            tier_grid = lean_family ? (unsigned)(2 * g_num_cu) : (unsigned)(g_num_cu * per_cu_resident) * (block.x / RT_TIER_THREADS > 0 ? block.x / RT_TIER_THREADS : 1u) / 2u;
+            if (tier_grid < 1u) tier_grid = 1u;
         }
     }
     out.kernel_variant = kernel * 1000 + lds_mode * 100 + s->tex_level * 10 + (s->spheres_only ? 1 : 0);
     out.workgroups = (int)grid.x; out.threads_per_group = (int)block.x; out.lds_bytes = (int)lds_bytes;
 
     HIPCHK(hipEventRecord(s->ev_start, stream));
-    // ---- cost-aware schedule (staged kernel): the frame is split at a sample boundary.
+    // ---- cost-aware schedule (staged kernel): the frame is split at sample boundaries.
     // A pixel's samples are one sequential chain (one XORWOW stream) and the dearest pixels of a frame trace ~10x the
     // mean number of rays, so the frame time is bounded by a few pixels' chains, not by throughput
-    // (tools/critical_chain.py: the worst 8 rows alone take as long as the whole frame).  Part 1 renders samples
-    // [0, S0) of every pixel and parks each pixel (XORWOW state, colour sum, rays traced) -- at a sample boundary no path
-    // is in flight, so that is the whole state.  With those measured costs part 2 renders samples [S0, ns):
+    // (tools/critical_chain.py: the worst 8 rows alone take as long as the whole frame).  Every part but the last parks
+    // each pixel at its end (XORWOW state, colour sum, rays traced: at a sample boundary no path is in flight, so that is
+    // the whole state), and every part is RANKED on what is known about the pixels' costs when it starts -- the
+    // calibration frame's prior for the first part, measured rays for the later ones:
     //   * 8x8 tiles are served in descending cost (longest first);
-    //   * pixels far above the mean go to a short list, dearest first, served by "sparse" workgroups at raised
-    //     priority: tier 0 (the very dearest, spheres-only scenes) a whole workgroup per pixel, tier 1 one live lane
-    //     per wave, tier 2 a few -- a lane's rays advance about twice as fast in a wave with few live lanes; ordinary
-    //     waves skip listed pixels.
+    //   * pixels far above the mean go to a short list, dearest first: tier 1 to the tier kernel (rt_kernel_tier.h, one
+    //     pixel per wave, on a stream of its own beside the main kernel), tier 2 to "sparse" main workgroups with a few live
+    //     lanes per wave at raised priority -- a lane's rays advance about twice as fast in a wave with few live lanes --,
+    //     tier 3 to ordinary lanes before any tile; ordinary waves skip listed pixels.
     // The ranking runs on the device (rt_rank.hip) and leaves the tier sizes in device memory, so the whole frame is
     // enqueued without a host round trip.  Scheduling only: every sample of every pixel is rendered exactly once, in
     // its pixel's stream order; frames are bit-identical with and without it (tests sweep the knobs).
     fp.tile_order = nullptr; fp.tile_cost = nullptr; fp.state_out = nullptr; fp.state_in = nullptr; fp.heavy_pixels = nullptr; fp.rank = nullptr;
-    fp.sample_begin = 0; fp.sample_end = f->ns;
+    fp.sample_begin = 0; fp.sample_end = f->ns; fp.fresh = 0;
     const size_t n_tiles = (size_t)fp.tiles_x * (size_t)tiles_y;
     const size_t n_pixels = (size_t)local_rows * (size_t)f->nx;
     enum { RT_HEAVY_CAP = 262144 };
     s->ranked_frame = false;
     HIPCHK(hipMemsetAsync(s->d_ray_counter, 0, 256, stream));
+    int part_index = 0;
+    // one part of the frame: the tier kernel (ranked parts of scenes that have tier data) on its own stream, forked from
+    // and joined to the caller's stream by events, and the main kernel
+    auto launch_part = [&](const rt_frame_params& q, dim3 grid_q, bool ranked) -> rt_status {
+        HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
+        const bool tiers = ranked && tier_possible;
+        const int pi = part_index++ & 3;
+        if (tiers) {
+            HIPCHK(hipEventRecord(s->ev_fork[pi], stream));
+            HIPCHK(hipStreamWaitEvent(s->tier_stream, s->ev_fork[pi], 0));
+            HIPCHK(s->spheres_only ? rt_launch_tier_spheres(s->tex_level, s->dev, q, dim3(tier_grid), tier_lds, s->tier_stream)
+                                   : rt_launch_tier_general(s->tex_level, s->need_uv, s->dev, q, dim3(tier_grid), tier_lds, s->tier_stream));
+            HIPCHK(hipEventRecord(s->ev_join[pi], s->tier_stream));
+        }
+        HIPCHK(launch_render(kernel, lds_mode, s, q, grid_q, block, lds_bytes, stream));
+        if (tiers) HIPCHK(hipStreamWaitEvent(stream, s->ev_join[pi], 0));
+        return RT_OK;
+    };
     if (g_opt.lpt && kernel == RT_KERNEL_STAGED && f->ns >= 2 * g_opt.split_samples && n_tiles >= 64 && n_pixels < (1ull << 31)) {
         if (s->tile_capacity < n_tiles || s->pixel_capacity < n_pixels || !s->d_rank) {
             for (void* p : {(void*)s->d_tile_cost, (void*)s->d_tile_order, (void*)s->d_state, (void*)s->d_heavy_list, (void*)s->d_heavy_pixels, (void*)s->d_rank})
@@ -1239,41 +1298,30 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             HIPCHK(hipMalloc((void**)&s->d_rank, sizeof(rt_rank_info)));
             s->tile_capacity = n_tiles; s->pixel_capacity = n_pixels;
         }
-        // One ranked part: three small kernels order the tiles, list the heavy pixels and size the tiers for the launch
-        // described by `q` (which resumes every pixel from d_state).  The grid is fixed here, before the sizes are known:
-        // the workgroups the ordinary queue needs plus the most the tiers may take; a workgroup that finds both its
-        // queues empty leaves at once.
+        // One ranking: three small kernels order the tiles, list the heavy pixels and size the tiers for the launch
+        // described by `q` (which resumes every pixel from d_state).  The grids are fixed here, before the sizes are known:
+        // the workgroups the ordinary queue needs plus the most the sparse tier may take; a workgroup that finds both its
+        // queues empty leaves at once.  `total` = the device counter holding the sum of the costs ranked on.
         const unsigned max_grid = (unsigned)(g_num_cu * per_cu_resident);
-        auto rank_pixels = [&](rt_frame_params& q, dim3& grid_q) -> rt_status {
+        auto rank_pixels = [&](rt_frame_params& q, dim3& grid_q, const unsigned long long* total) -> rt_status {
             // Effective tier sizes by the share of the frame this call renders (1/N in an N-GPU run): the fewer pixels a
             // rank has per lane, the more of them can afford a wave of their own.  Measured on rank-local renders of the
-            // headline frame (tools/partition_time.py; profiles/r02_schedule_experiments.log, "tier 1 after the slot
-            // unions"): since trace_wave() skips the leaf slots a ray cannot meet, a wave per pixel (tier 1) beats a
-            // workgroup per pixel (tier 0, trace_group) at every share -- tier 0 stays available through the options.
-            int e_tier0_pixels = g_opt.tier0_pixels, e_tier0_factor = g_opt.tier0_factor_x10, e_tier1_pixels = g_opt.tier1_pixels,
-                e_tier1_factor = g_opt.tier1_factor_x10, e_tier1_depth = g_opt.tier1_depth, e_heavy_factor = g_opt.heavy_factor_x10,
-                e_sparse_factor = g_opt.sparse_factor_x10, e_sparse_percent = g_opt.sparse_wg_percent, e_work_percent = g_opt.sparse_work_percent;
-            if (g_opt.tier0_auto) {
-                const double share = (double)n_pixels / ((double)f->nx * (double)f->ny);
-                e_tier0_pixels = 0;
-                if (tier0_possible) {          // trace_wave() is there (spheres-only scene resident in LDS)
-                    // keyed by pixels per resident lane (the 1200x800 frame: 3.7 whole, 1.8 / 0.9 / 0.5 for a half, a quarter,
-                    // an eighth; a quarter of 1920x1080 is 2.0): what matters is how empty the machine is, not the fraction
-                    const double per_lane = (double)n_pixels / ((double)max_grid * (double)block.x);
-                    if (per_lane > 2.75) { /* the defaults */ }
-                    else if (per_lane > 1.375) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; }
-                    else if (per_lane > 0.6875) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; e_work_percent = 20; }
-                    else { e_tier1_pixels = 8192; e_tier1_factor = 20; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 15; e_sparse_percent = 80; e_work_percent = 40; }
-                } else {                       // tier 1 is the 64-nodes-at-a-time walk there: only the very dearest pixels
-                    e_tier1_factor = 70; e_tier1_pixels = 256; e_tier1_depth = 1;
-                    if (share > 0.75) { }
-                    else if (share > 0.375) { e_heavy_factor = 20; e_sparse_factor = 35; e_sparse_percent = 50; }
-                    else { e_tier1_pixels = 0; e_heavy_factor = 20; e_sparse_factor = 20; e_sparse_percent = 80; }
-                }
+            // headline frame (tools/partition_time.py).
+            int e_tier1_pixels = g_opt.tier1_pixels, e_tier1_factor = g_opt.tier1_factor_x10, e_tier1_depth = g_opt.tier1_depth,
+                e_heavy_factor = g_opt.heavy_factor_x10, e_sparse_factor = g_opt.sparse_factor_x10, e_sparse_percent = g_opt.sparse_wg_percent,
+                e_work_percent = g_opt.sparse_work_percent;
+            if (g_opt.tier_auto) {
+                // keyed by pixels per resident lane (the 1200x800 frame: 3.7 whole, 1.8 / 0.9 / 0.5 for a half, a quarter,
+                // an eighth; a quarter of 1920x1080 is 2.0): what matters is how empty the machine is, not the fraction
+                const double per_lane = (double)n_pixels / ((double)max_grid * (double)block.x);
+                if (per_lane > 2.75) { /* the defaults */ }
+                else if (per_lane > 1.375) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; }
+                else if (per_lane > 0.6875) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; e_work_percent = 20; }
+                else { e_tier1_pixels = 8192; e_tier1_factor = 20; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 15; e_sparse_percent = 80; e_work_percent = 40; }
             }
             rt_rank_params rp;
             memset(&rp, 0, sizeof(rp));
-            rp.state = s->d_state; rp.tile_cost = s->d_tile_cost; rp.tile_order = s->d_tile_order; rp.ray_counter = s->d_ray_counter;
+            rp.state = s->d_state; rp.tile_cost = s->d_tile_cost; rp.tile_order = s->d_tile_order; rp.ray_counter = total;
             rp.heavy_list = s->d_heavy_list; rp.heavy_pixels = s->d_heavy_pixels; rp.info = s->d_rank;
             rp.n_pixels = (uint32_t)n_pixels; rp.n_tiles = (uint32_t)n_tiles; rp.heavy_cap = RT_HEAVY_CAP;
             rp.max_grid = max_grid; rp.waves_per_wg = block.x / 64u;
@@ -1282,37 +1330,55 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             rp.semi_stride = g_opt.semi_stride;
             rp.sparse_percent = e_sparse_percent;
             rp.sparse_work_percent = e_work_percent;
-            rp.tier0_possible = tier0_possible ? 1 : 0;
-            rp.tier0_pixels = e_tier0_pixels; rp.tier1_pixels = e_tier1_pixels; rp.tier1_depth = e_tier1_depth;
+            rp.tier_possible = tier_possible ? 1 : 0;
+            rp.tier1_pixels = e_tier1_pixels; rp.tier1_depth = e_tier1_depth;
+            rp.tier_wgs_cap = (int32_t)tier_grid; rp.tier_waves_per_main_wg = tier_waves_per_main_wg;
             rp.nx = f->nx; rp.smooth_percent = g_opt.cost_smooth_percent;
             if (e_sparse_factor < e_heavy_factor) e_sparse_factor = e_heavy_factor;
-            rp.heavy_factor = (float)e_heavy_factor / 10.0f; rp.sparse_factor = (float)e_sparse_factor / 10.0f; rp.tier1_factor = (float)e_tier1_factor / 10.0f; rp.tier0_factor = (float)e_tier0_factor / 10.0f;
+            rp.heavy_factor = (float)e_heavy_factor / 10.0f; rp.sparse_factor = (float)e_sparse_factor / 10.0f; rp.tier1_factor = (float)e_tier1_factor / 10.0f;
             HIPCHK(rt_launch_rank(rp, stream));
             q.tile_order = s->d_tile_order; q.heavy_pixels = s->d_heavy_pixels; q.rank = s->d_rank;
-            unsigned total = rp.normal_need + (rp.sparse_stride > 0 ? max_grid * (unsigned)e_sparse_percent / 100u : 0u);
-            if (total > max_grid) total = max_grid;
-            if (total < 1u) total = 1u;
-            grid_q = dim3(total);
+            unsigned total_wgs = rp.normal_need + (rp.sparse_stride > 0 ? max_grid * (unsigned)e_sparse_percent / 100u : 0u);
+            if (tier_waves_per_main_wg > 0 && tier_possible) total_wgs = max_grid;      // (workgroups that make room for the tier kernel are part of the grid)
+            if (total_wgs > max_grid) total_wgs = max_grid;
+            if (total_wgs < 1u) total_wgs = 1u;
+            grid_q = dim3(total_wgs);
             return RT_OK;
         };
-        // ---- part 1: samples [0, S_a) -- every pixel alike (nothing is known yet); S_a = presplit_samples, or S0
+        // ---- part 1: samples [0, S_a); S_a = presplit_samples, or S0.  Nothing has been measured yet; with the cost prior
+        // (rt_prior_kernel: the calibration frame's rays per pixel, scaled to this frame) the part is ranked all the same,
+        // so that the dearest chains start on tier waves at sample 0 instead of running at an ordinary lane's pace.
         const int first_end = (g_opt.presplit_samples > 0 && g_opt.presplit_samples < g_opt.split_samples) ? g_opt.presplit_samples : g_opt.split_samples;
         HIPCHK(hipMemsetAsync(s->d_tile_cost, 0, n_tiles * sizeof(unsigned int), stream));
-        HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
         rt_frame_params p1 = fp;
+        dim3 grid1 = grid;
         p1.sample_end = first_end; p1.state_out = s->d_state; p1.tile_cost = s->d_tile_cost;
-        HIPCHK(launch_render(kernel, lds_mode, s, p1, grid, block, lds_bytes, stream));
-        // ---- part 1b: samples [S_a, S0), already with tiers ranked on the first S_a samples.  Part 1 is bound by the
-        // chains of the dearest pixels run at an ordinary wave's pace; a short first look is enough to find most of them.
+        bool ranked1 = false;
+        if (g_opt.prior && s->d_cal_cost && s->cal_nx > 0 && s->cal_ny > 0) {
+            rt_prior_params pp;
+            memset(&pp, 0, sizeof(pp));
+            pp.state = s->d_state; pp.tile_cost = s->d_tile_cost; pp.total = s->d_ray_counter + 3;
+            pp.cal_cost = s->d_cal_cost; pp.cal_nx = s->cal_nx; pp.cal_ny = s->cal_ny;
+            pp.nx = f->nx; pp.ny = f->ny; pp.local_rows = local_rows; pp.tiles_x = fp.tiles_x;
+            pp.tile_rows = f->tile_rows; pp.tile_first = f->tile_first; pp.tile_stride = f->tile_stride;
+            HIPCHK(rt_launch_prior(pp, stream));
+            p1.state_in = s->d_state; p1.fresh = 1;
+            const rt_status st1 = rank_pixels(p1, grid1, s->d_ray_counter + 3);
+            if (st1 != RT_OK) return st1;
+            HIPCHK(hipMemsetAsync(s->d_tile_cost, 0, n_tiles * sizeof(unsigned int), stream));   // from here on: measured rays
+            ranked1 = true;
+        }
+        { const rt_status st1 = launch_part(p1, grid1, ranked1); if (st1 != RT_OK) return st1; }
+        // ---- part 1b: samples [S_a, S0), with tiers ranked on the first S_a samples.
         if (first_end < g_opt.split_samples) {
             rt_frame_params p2 = fp;
             dim3 grid2 = grid;
             p2.sample_begin = first_end; p2.sample_end = g_opt.split_samples;
             p2.state_in = s->d_state; p2.state_out = s->d_state; p2.tile_cost = s->d_tile_cost;
-            const rt_status st2 = rank_pixels(p2, grid2);
+            rt_status st2 = rank_pixels(p2, grid2, s->d_ray_counter);
             if (st2 != RT_OK) return st2;
-            HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
-            HIPCHK(launch_render(kernel, lds_mode, s, p2, grid2, block, lds_bytes, stream));
+            st2 = launch_part(p2, grid2, true);
+            if (st2 != RT_OK) return st2;
         }
         // ---- part 1c (optional): samples [S0, S1), ranked on the first S0 samples; the last part is then ranked again on
         // S1 samples.  A pixel's cost over 32 samples is a noisy estimate of its cost over 500 (paths through glass are
@@ -1323,27 +1389,26 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             dim3 grid3 = grid;
             p3.sample_begin = g_opt.split_samples; p3.sample_end = g_opt.resplit_samples;
             p3.state_in = s->d_state; p3.state_out = s->d_state; p3.tile_cost = s->d_tile_cost;
-            const rt_status st2 = rank_pixels(p3, grid3);
+            rt_status st2 = rank_pixels(p3, grid3, s->d_ray_counter);
             if (st2 != RT_OK) return st2;
-            HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
-            HIPCHK(launch_render(kernel, lds_mode, s, p3, grid3, block, lds_bytes, stream));
+            st2 = launch_part(p3, grid3, true);
+            if (st2 != RT_OK) return st2;
             last_begin = g_opt.resplit_samples;
         }
-        // ---- part 2: samples [S1 or S0, ns), ranked on everything rendered so far
+        // ---- last part: samples [S1 or S0, ns), ranked on everything rendered so far
         fp.state_in = s->d_state; fp.sample_begin = last_begin;
-        const rt_status st3 = rank_pixels(fp, grid);
+        const rt_status st3 = rank_pixels(fp, grid, s->d_ray_counter);
         if (st3 != RT_OK) return st3;
         out.workgroups = (int)grid.x;
         s->ranked_frame = true;
     }
     out.reserved = 0;
-    HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));   // the ray counter keeps part 1's rays
 #ifdef RT_DIAG
     // wave-end histograms of the frame's last launch only (rt_debug_wave_ends)
     HIPCHK(hipMemsetAsync(s->d_ray_counter + RT_DIAG_T0_SLOT, 0xFF, 8, stream));
     HIPCHK(hipMemsetAsync(s->d_ray_counter + RT_DIAG_HIST_SLOT, 0, (size_t)(2 * RT_DIAG_BINS + 7 + 2 * RT_DIAG_MAX_WAVES) * 8, stream));
 #endif
-    HIPCHK(launch_render(kernel, lds_mode, s, fp, grid, block, lds_bytes, stream));
+    { const rt_status stl = launch_part(fp, grid, s->ranked_frame); if (stl != RT_OK) return stl; }
     HIPCHK(hipEventRecord(s->ev_stop, stream));
     s->frame_pending = true;
     s->pending_stream = stream;

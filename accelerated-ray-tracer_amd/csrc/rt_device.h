@@ -1,5 +1,5 @@
-// rt_device.h -- kernel argument blocks shared by rt_device.hip (kernels) and
-// rt_abi.hip (the C-ABI implementation).  Internal to librt_mi355x.so.
+// rt_device.h -- kernel argument blocks shared by the kernel translation units (rt_kernel_pixel.hip, rt_staged_*.hip,
+// rt_tier_*.hip, rt_rank.hip) and rt_abi.hip (the C-ABI implementation).  Internal to librt_mi355x.so.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -9,22 +9,28 @@
 #define RT_PERSISTENT_THREADS 512   // default workgroup size of the staged kernel
 // Register budgets of the staged kernel families, as launch bounds (threads per workgroup the code may be launched
 // with, waves per SIMD it must leave room for).  "Lean" = spheres-only scenes without procedural / image textures (the
-// headline kernel): 94 VGPRs once the double-precision transcendentals are out of line, but more than 4 waves per SIMD
-// only slow the dearest pixels' chains down (profiles/r02g_occupancy_sweep.log: 2 x 640 threads 131 ms, 2 x 512 110 ms).
-// Everything else (quads / boxes / media, Perlin / image textures) fits 168 VGPRs without spilling: 3 waves per SIMD.
+// headline kernel): 94 VGPRs, no scratch (profiles/r03_kernel_resources.md) -- the double-precision transcendentals are out
+// of line and the one-pixel-per-wave loops live in their own kernel (rt_kernel_tier.h).  It is launched 2 x 512 threads per
+// CU = 4 waves per SIMD: 4 x 96 registers leave 128 of a SIMD's 512 for one co-resident wave of the tier kernel.
+// Everything else (quads / boxes / media, Perlin / image textures) is budgeted 168 VGPRs: 3 waves per SIMD.
 #ifndef RT_LEAN_MIN_WAVES
 #define RT_LEAN_MIN_WAVES 4
 #endif
+#ifndef RT_LEAN_MAX_THREADS
 #define RT_LEAN_MAX_THREADS 512
+#endif
 #define RT_HEAVY_MAX_THREADS 768
 #define RT_HEAVY_MIN_WAVES 3
 
-// kernel ids keep their round-1 numbers (1 = persistent and 2 = parked were the steps between 0 and 3; removed)
+// the tier kernel (rt_kernel_tier.h): workgroups of four waves, one per SIMD; <= 128 VGPRs for the lean family (co-resident
+// with the main kernel's 4 x 96), 168 for the others (its workgroups take the slots main workgroups vacate: main_skip_wgs)
+#define RT_TIER_THREADS 256
+// kernel ids keep their round-1 numbers (1 = persistent, 2 = parked, 4 = wavefront were experiments; removed)
 // the statistics block behind rt_frame_params.ray_counter (64-bit words): [0] rays, [1..16] stage counters and [32..] the
-// wave-end histograms of diagnostic builds (-DRT_DIAG), [31] the wavefront kernel's iteration-cap flag
+// wave-end histograms of diagnostic builds (-DRT_DIAG), [3] the sum of the cost prior (rt_prior_kernel)
 enum { RT_DIAG_BINS = 192, RT_DIAG_T0_SLOT = 32, RT_DIAG_HIST_SLOT = 33, RT_DIAG_WAVE_SLOT = 33 + 2 * 192 + 7, RT_DIAG_MAX_WAVES = 8192,
        RT_COUNTER_BYTES = (33 + 2 * 192 + 7 + 2 * 8192) * 8 };   // + per wave: two words about the lane that finished last
-enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_STAGED = 3, RT_KERNEL_WAVEFRONT = 4 };
+enum { RT_KERNEL_PIXEL = 0, RT_KERNEL_STAGED = 3 };
 
 // A pixel parked at a sample boundary (split frames): XORWOW state, colour sum, rays traced so far.
 struct rt_pixel_state {
@@ -39,16 +45,17 @@ struct rt_pixel_state {
 struct rt_rank_info {
     uint32_t heavy_items;        // entries of heavy_pixels (dearest first); 0 = no list
     uint32_t heavy_threshold;    // pixels whose parked cost is >= this are in the list (ordinary waves skip them)
-    uint32_t tier0_items;        // leading entries served one per WORKGROUP (tier 0)
-    uint32_t tier1_items;        // following entries served one per WAVE (tier 1)
+    uint32_t tier1_items;        // leading entries served one per WAVE by the tier kernel (tier 1)
     uint32_t tier2_items;        // following entries served by sparse waves (tier 2); the REST of the list (tier 3) is taken by
                                  // ordinary lanes before anything else, so that every dear pixel's chain starts at once
-    int32_t tier0_wgs, tier1_wgs;   // workgroups [0, tier0_wgs) are tier 0, the next tier1_wgs tier 1
-    int32_t sparse_wgs;          // workgroups [0, sparse_wgs) start in sparse mode (tiers 0, 1, 2)
+    int32_t tier1_wgs;           // workgroups of the TIER kernel that have work (the rest of its grid leaves at once)
+    int32_t main_skip_wgs;       // workgroups [0, main_skip_wgs) of the MAIN kernel leave at once: their slots are the tier
+                                 // kernel's (kernel families whose register budget leaves no room beside a full main grid)
+    int32_t sparse_wgs;          // main workgroups [main_skip_wgs, main_skip_wgs + sparse_wgs) start in sparse mode (tier 2)
     int32_t sparse_stride;       // sparse waves: every sparse_stride-th lane takes a pixel
     int32_t semi_wgs;            // the next semi_wgs workgroups serve tier 3 with every semi_stride-th lane (0: ordinary lanes take tier 3)
     int32_t semi_stride;
-    uint32_t threshold0, threshold1;   // costs that qualify for tier 0 / tier 1 (set with heavy_threshold by the first ranking kernel)
+    uint32_t threshold1;         // cost that qualifies for tier 1 (set with heavy_threshold by the first ranking kernel)
     uint32_t threshold2;         // cost that qualifies for the sparse waves (tier 2)
     uint32_t collected;          // entries rt_collect_heavy_kernel appended (may exceed the capacity: then there is no list)
 };
@@ -68,12 +75,15 @@ struct rt_rank_params {
     int32_t semi_stride;                 // lanes per pixel in the workgroups that serve tier 3 (0 = ordinary lanes take tier 3 first)
     int32_t sparse_percent;              // at most this share of max_grid starts in sparse mode
     int32_t sparse_work_percent;         // ... and tiers 0-2 together hold at most this share of the frame's rays so far
-    int32_t tier0_possible;              // tier 0 needs a spheres-only scene resident in LDS
-    int32_t tier0_pixels, tier1_pixels;  // caps on the tier sizes
+    int32_t tier_possible;               // the scene has tier data (leaf arrays, rt_scene_dev) and the tier kernel is launched
+    int32_t tier1_pixels;                // cap on tier 1
     int32_t tier1_depth;                 // pixels a tier-1 wave is meant to take, one after the other
+    int32_t tier_wgs_cap;                // the tier kernel's grid (fixed on the host before the sizes are known)
+    int32_t tier_waves_per_main_wg;      // 0: tier workgroups fit beside a full main grid; else: tier waves that fit into the
+                                         // slot of one main workgroup (main_skip_wgs = tier waves / this, rounded up)
     int32_t nx, smooth_percent;          // cost estimate of a pixel = max(own, smooth_percent % of its dearest 4-neighbour's); nx = pixels per local row
-    float heavy_factor, sparse_factor, tier1_factor, tier0_factor;   // cost thresholds as multiples of the mean cost per pixel:
-                                         // >= heavy: in the list at all; >= sparse: tier 2; >= tier1 / tier0: those tiers
+    float heavy_factor, sparse_factor, tier1_factor;   // cost thresholds as multiples of the mean cost per pixel:
+                                         // >= heavy: in the list at all; >= sparse: tier 2; >= tier1: tier 1
 };
 
 // Device encoding of a node's two links (both node arrays below; rt_abi.hip device_nodes()): `skip` holds ~skip and
@@ -95,6 +105,16 @@ struct rt_scene_dev {
     const rt_texture* textures;
     const uint8_t* images;
     int32_t n_nodes, n_nodes_ref, n_spheres, n_materials, n_textures;
+    // tier data (rt_kernel_tier.h; built by rt_scene_create from the walk array, null when the scene has none): the leaves
+    // of the walk array in depth-first order as two float4 arrays padded to a multiple of 64 -- leaf_lo[q] = (bmin, prim as
+    // int bits; -1 in the padding), leaf_hi[q] = (bmax, 0) --, per 64 leaves the union of their boxes (slot_ranges: 8 floats
+    // each: lo, hi, 0, 0), and the ordinals of the (at most two) constant_medium leaves
+    const float4* leaf_lo;
+    const float4* leaf_hi;
+    const float* slot_ranges;
+    int32_t n_leaves, n_slots;
+    int32_t n_media_leaves;
+    int32_t media_ord[2];
     rt_camera camera;
 };
 
@@ -102,6 +122,7 @@ struct rt_frame_params {
     float* fb;                            // compact local rows, nx*3 floats each
     unsigned long long* ray_counter;      // += rays traced
     unsigned int* work_counter;           // persistent kernel's pixel queue head
+    unsigned int* pixel_cost;             // calibration pass (kernel 0 only): rays traced per pixel, nx * local_rows; null otherwise
     unsigned int* node_pass;              // calibration pass (kernel 0 only): += 1 per box test of nodes_ref[i] that passed; null otherwise
     int32_t node_pass_lds;                // ... collected in LDS per workgroup (n_nodes_ref x 4 B of dynamic LDS) and flushed at its end
     float* ray_sample;                    // calibration pass: every ray_sample_stride-th ray as (origin, direction, t of its hit or FLT_MAX), 7 floats each
@@ -113,7 +134,9 @@ struct rt_frame_params {
     int32_t sample_begin, sample_end;     // samples [sample_begin, sample_end) are rendered by this launch; ns is the frame's total
     const unsigned int* heavy_pixels;     // ranked launches: local pixel ids (lrow * nx + i) of the heavy pixels, dearest first
     const rt_rank_info* rank;             // ranked launches: tier sizes left by the ranking kernels; null = no heavy list, no tiers
-    uint32_t tier0_lds_offset;            // tier 0: byte offset of the workgroup's scratch (leaf list, reduction slots) in dynamic LDS
+    int32_t fresh;                        // ranked FIRST part (tiers from the cost prior): state_in only carries the prior's cost and
+                                          // list flag; pixels start from their seed with an empty colour sum
+    int32_t tier_lds_spheres, tier_lds_materials;   // tier kernel: which records besides the leaf arrays its LDS image holds
     uint64_t seed_base;
     int32_t nx, ny, ns;
     float gamma;
@@ -131,14 +154,29 @@ struct rt_frame_params {
     int32_t box_threshold, medium_threshold;   // staged kernel, general scenes: parked box/instance and medium lanes that trigger their leaf tests
     int32_t diel_threshold;               // staged kernel: dielectric hits that trigger their stage
     int32_t newpath_threshold;            // staged kernel: ended paths that trigger the new-path stage
-    int32_t wf_slots;                     // wavefront kernel: ray slots per workgroup (multiple of 64)
-    uint32_t wf_max_iterations;           // wavefront kernel: safety cap on workgroup iterations
-    int32_t wf_pause_lanes;               // wavefront kernel: a wave with fewer walking lanes re-queues them once READY is empty
 };
 
 // the three ranking kernels of one ranked part, enqueued on `st` (no host synchronisation)
 hipError_t rt_launch_rank(const rt_rank_params& rp, hipStream_t st);
-#define RT_WF_BYTES_PER_SLOT (31 * 4 + 5 * 2)   /* 20 float + 11 int arrays, 5 u16 lists */
+// the cost prior of a ranked first part (rt_rank.hip): d_state[p].cost and tile_cost from the calibration frame's per-pixel rays
+struct rt_prior_params {
+    rt_pixel_state* state;
+    unsigned int* tile_cost;
+    unsigned long long* total;            // += sum of the priors (what the ranking kernels read as "rays so far")
+    const unsigned int* cal_cost;         // rays per calibration pixel, cal_nx x cal_ny, row 0 = bottom
+    int32_t cal_nx, cal_ny;
+    int32_t nx, ny, local_rows, tiles_x;
+    int32_t tile_rows, tile_first, tile_stride;
+};
+hipError_t rt_launch_prior(const rt_prior_params& pp, hipStream_t st);
+// bytes of the tier kernel's LDS image (rt_kernel_tier.h stages exactly this): leaf arrays + slot unions, then spheres,
+// then materials + textures where the launch plan (rt_abi.hip) says so
+static inline size_t rt_tier_lds_bytes(int n_slots, int n_spheres, bool spheres, int n_materials, int n_textures, bool materials) {
+    size_t b = (size_t)n_slots * 64 * 32 + (size_t)n_slots * 32;
+    if (spheres) b += (size_t)n_spheres * sizeof(rt_sphere);
+    if (materials) b += (size_t)n_materials * sizeof(rt_material) + (size_t)n_textures * sizeof(rt_texture);
+    return b;
+}
 
 // Launchers, one per translation unit (each returns the launch's hipError_t, including a failed
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize)).  tex_level: 0 = every material colour is inline, 1 = solid +
@@ -154,5 +192,6 @@ hipError_t rt_launch_staged_general(int lds_mode, const rt_scene_dev& sd, const 
                                     size_t lds, hipStream_t st);
 hipError_t rt_launch_staged_general_tex(int lds_mode, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block,
                                         size_t lds, hipStream_t st);
-hipError_t rt_launch_wavefront(int lds_mode, int tex_level, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block,
-                               size_t lds_bytes, hipStream_t stream);
+// the tier kernel of a ranked launch (rt_tier_*.hip); *vgprs_out (optional) = the instantiation's register count
+hipError_t rt_launch_tier_spheres(int tex_level, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st);
+hipError_t rt_launch_tier_general(int tex_level, bool need_uv, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st);

@@ -700,63 +700,7 @@ DEV bool inv_is_finite(const f3 inv) {
     return fabsf(inv.x) < INFINITY && fabsf(inv.y) < INFINITY && fabsf(inv.z) < INFINITY;
 }
 
-// One ray, the whole wave: the 64 lanes test 64 consecutive nodes of the depth-first array at once, then the walk the
-// reference would take through them (box hit -> next index or leaf test, box miss -> skip link) is replayed with scalar
-// bit tests on the ballot, v_readlane for the skip links.  Used by tier-1 waves, which hold a single pixel whose
-// sequential chain bounds the frame time: a lone lane's traversal is LDS-latency bound (one dependent node read per
-// step); here one pair of wide reads serves several steps.  Every box is still compared with the closest hit that the
-// reference would have at that visit: the batch is abandoned as soon as a leaf test changes it.  All arguments are
-// wave-uniform (every lane carries the same ray); the result is identical in all lanes.
-template <bool SPHERES_ONLY>
-DEV bool trace_wide(const SceneView& sc, const Ray& r, HitInfo& best) {
-    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    const float tmin = 0.001f;
-    best.t = FLT_MAX; best.prim = -1; best.inst = -1;
-    const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
-    const int n = sc.n_nodes;
-    const int lane = (int)(threadIdx.x & 63u);
-    int i = 0;
-    while (i < n) {
-        const int idx = i + lane;
-        const bool valid = idx < n;
-        const float4 a = nodes4[2 * (valid ? idx : 0)], b = nodes4[2 * (valid ? idx : 0) + 1];
-        const bool pass = valid && slab_test(a, b, r.o, inv, tmin, best.t);
-        const int my_skip = RT_NODE_SKIP(__float_as_int(a.w)), my_prim = __float_as_int(b.w);
-        const unsigned long long pass_mask = __ballot(pass);
-        const unsigned long long leaf_mask = __ballot(valid && my_prim >= 0);
-        const int end = (i + 64 < n) ? i + 64 : n;
-        int j = i;
-        while (j < end) {
-            const int bit = j - i;
-            if (!((pass_mask >> bit) & 1ull)) { j = __builtin_amdgcn_readlane(my_skip, bit); continue; }
-            if ((leaf_mask >> bit) & 1ull) {
-                const float before = best.t;
-                const int32_t before_prim = best.prim;
-                leaf_test<SPHERES_ONLY, true>(sc, __builtin_amdgcn_readlane(my_prim, bit), r, tmin, best);
-                j = __builtin_amdgcn_readlane(my_skip, bit);
-                if (best.t != before || best.prim != before_prim) break;   // later boxes must see the new limit
-            } else {
-                j = j + 1;
-            }
-        }
-        i = j;
-    }
-    return best.prim >= 0;
-}
-
-
-// One ray, the whole workgroup ("tier 0", spheres-only scenes): every leaf of the tree is tested at once, one per
-// thread -- its own box with no limit, then its sphere -- and the closest hit is the minimum of (t, node index) over the
-// workgroup.  Why this is the reference's answer for finite 1/d:
-//   * a leaf the reference tests has a box that passes with the limit of that moment, hence with none: the set tested
-//     here is a superset of the reference's;
-//   * a box contains its descendants' boxes and the slab test is monotone in the box, so a leaf whose own box passes has
-//     ancestors that pass; the reference can only skip it because an earlier hit b satisfies b <= T_A <= T_leaf (entry
-//     distances).  The winner here has t <= every other candidate's t, so the b in force when the reference reaches its
-//     ancestors is >= t; if t > T_leaf (checked below) then b > T_A for every ancestor and the reference tests it too;
-//   * the reference keeps a hit only if t < closest, i.e. the minimum with ties to the first visited = lowest index.
-// A candidate hit at or before its own box's entry distance (rounding on a grazing ray) or a zero direction component
-// falls back to the reference's walk, replayed by every thread.  One barrier per ray (slots are double-buffered).
+// the interval of the ray inside a box, no upper limit (rt_kernel_tier.h: trace_wave)
 DEV void slab_interval(const float4 lo_skip, const float4 hi_prim, const f3 o, const f3 inv, float tmin, float& t_enter, float& t_exit) {
     float tmax = FLT_MAX;
     float t0 = (lo_skip.x - o.x) * inv.x, t1 = (hi_prim.x - o.x) * inv.x;
@@ -772,148 +716,6 @@ DEV void slab_interval(const float4 lo_skip, const float4 hi_prim, const f3 o, c
     tmin = t0 > tmin ? t0 : tmin;
     tmax = t1 < tmax ? t1 : tmax;
     t_enter = tmin; t_exit = tmax;
-}
-DEV bool trace_group(const SceneView& sc, const Ray& r, HitInfo& best, const unsigned int* leaves, int n_leaves,
-                     unsigned long long* slots, int& parity) {
-    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    const float tmin = 0.001f;
-    if (!inv_is_finite(inv)) return trace<true>(sc, r, best);   // workgroup-uniform
-    const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
-    unsigned long long key = ~0ull;
-    bool anomaly = false;
-    for (int q = (int)threadIdx.x; q < n_leaves; q += (int)blockDim.x) {
-        const int node = (int)leaves[q];
-        const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
-        float t_enter, t_exit;
-        slab_interval(a, b, r.o, inv, tmin, t_enter, t_exit);
-        if (!(t_exit <= t_enter)) {
-            float t;
-            if (sphere_test(sc.spheres[RT_PRIM_INDEX(__float_as_int(b.w))], r, tmin, FLT_MAX, t)) {
-                if (!(t > t_enter)) anomaly = true;
-                const unsigned long long k = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)node;
-                if (k < key) key = k;
-            }
-        }
-    }
-    if (anomaly) key = 0ull;
-    unsigned long long have = __ballot(key != ~0ull);
-    unsigned long long wkey = ~0ull;
-    const int lo = (int)(unsigned int)key, hi = (int)(unsigned int)(key >> 32);
-    while (have != 0ull) {
-        const int k = __ffsll((long long)have) - 1;
-        have &= have - 1ull;
-        const unsigned long long kk = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(hi, k) << 32) |
-                                      (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(lo, k);
-        if (kk < wkey) wkey = kk;
-    }
-    unsigned long long* mine = slots + parity * 16;
-    if ((threadIdx.x & 63u) == 0u) mine[threadIdx.x >> 6] = wkey;
-    __syncthreads();
-    unsigned long long m = ~0ull;
-    const int n_waves = (int)(blockDim.x >> 6);
-    for (int w = 0; w < n_waves; ++w) { const unsigned long long v = mine[w]; if (v < m) m = v; }
-    parity ^= 1;
-    if (m == 0ull) return trace<true>(sc, r, best);   // a grazing hit at or before its box's entry: the reference's walk decides
-    best.inst = -1;
-    if (m == ~0ull) { best.t = FLT_MAX; best.prim = -1; return false; }
-    best.t = __uint_as_float((unsigned int)(m >> 32));
-    best.prim = sc.nodes[(int)(unsigned int)m].prim;
-    return true;
-}
-
-
-// One ray, one wave ("tier 1", spheres-only scenes with at most 64 * RT_WAVE_SLOTS leaves): every leaf's box lives in
-// the registers of one lane (slot k of lane l holds leaf 64 * k + l of the depth-first leaf list), so a ray is
-// RT_WAVE_SLOTS register-resident slab tests per lane, a sphere test (one LDS read) for the few leaves whose box passes,
-// and a minimum over the wave -- no dependent chain of LDS round trips at all.  A sequential walk costs ~390 cycles per
-// node under load (one LDS round trip + the slab arithmetic), ~11,700 per ray of the headline scene; this is ~2,500.
-// Same argument and same safeguards as trace_group(): the closest hit is the minimum of (t, leaf ordinal) over all
-// leaves whose own box passes without a limit; a candidate at or before its own box's entry distance (rounding on a
-// grazing ray) or a zero direction component hands the ray to the reference's walk.  The leaf list is in depth-first
-// order, so the leaf ordinal orders ties exactly as the node index does.
-#define RT_WAVE_SLOTS 8
-struct WaveLeaves {
-    float lo[RT_WAVE_SLOTS][3], hi[RT_WAVE_SLOTS][3];
-    int32_t prim[RT_WAVE_SLOTS];      // the leaf's sphere (< 0: no leaf in this slot)
-};
-DEV void wave_leaves_load(const SceneView& sc, const unsigned int* leaves, int n_leaves, WaveLeaves& w) {
-    const int lane = (int)(threadIdx.x & 63u);
-#pragma unroll
-    for (int k = 0; k < RT_WAVE_SLOTS; ++k) {
-        const int q = k * 64 + lane;
-        w.prim[k] = -1;
-        w.lo[k][0] = w.lo[k][1] = w.lo[k][2] = 0.f; w.hi[k][0] = w.hi[k][1] = w.hi[k][2] = 0.f;
-        if (q < n_leaves) {
-            const rt_node nd = sc.nodes[leaves[q]];
-            w.lo[k][0] = nd.bmin[0]; w.lo[k][1] = nd.bmin[1]; w.lo[k][2] = nd.bmin[2];
-            w.hi[k][0] = nd.bmax[0]; w.hi[k][1] = nd.bmax[1]; w.hi[k][2] = nd.bmax[2];
-            w.prim[k] = nd.prim;
-        }
-    }
-}
-// `ranges` (LDS, or null): per register slot k the union of the boxes of leaves 64 k .. 64 k + 63 (eight floats each: lo,
-// hi, padding) -- the leaves are in depth-first order, so a slot is a compact patch of the scene.  Lane k tests slot k's
-// union first and a slot whose union the ray misses is skipped: by the same monotonicity that carries the walk array
-//  none of its leaves' boxes could pass.
-DEV bool trace_wave(const SceneView& sc, const Ray& r, HitInfo& best, const WaveLeaves& w, int n_leaves, const float* ranges = nullptr) {
-    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    const float tmin = 0.001f;
-    if (!inv_is_finite(inv)) return trace<true>(sc, r, best);   // wave-uniform
-    const float a = dot(r.d, r.d);
-    const int lane = (int)(threadIdx.x & 63u);
-    unsigned int slot_mask = 0xFFFFFFFFu;
-    if (ranges) {
-        bool meets = false;
-        if (lane < RT_WAVE_SLOTS) {
-            const float* q = ranges + lane * 8;
-            float t_enter, t_exit;
-            slab_interval(make_float4(q[0], q[1], q[2], 0.f), make_float4(q[3], q[4], q[5], 0.f), r.o, inv, tmin, t_enter, t_exit);
-            meets = !(t_exit <= t_enter);
-        }
-        slot_mask = (unsigned int)__ballot(meets);
-    }
-    unsigned long long key = ~0ull;
-    bool anomaly = false;
-#pragma unroll
-    for (int k = 0; k < RT_WAVE_SLOTS; ++k) {
-        if (k * 64 >= n_leaves) break;                           // wave-uniform
-        if (!((slot_mask >> k) & 1u)) continue;                  // wave-uniform: the ray misses this slot's union box
-        const float4 lo4 = make_float4(w.lo[k][0], w.lo[k][1], w.lo[k][2], 0.f), hi4 = make_float4(w.hi[k][0], w.hi[k][1], w.hi[k][2], 0.f);
-        float t_enter, t_exit;
-        slab_interval(lo4, hi4, r.o, inv, tmin, t_enter, t_exit);
-        const bool pass = w.prim[k] >= 0 && !(t_exit <= t_enter);
-        if (__ballot(pass) != 0ull) {
-            if (pass) {
-                float t;
-                if (sphere_test_a(sc.spheres[RT_PRIM_INDEX(w.prim[k])], r, a, tmin, FLT_MAX, t)) {
-                    if (!(t > t_enter)) anomaly = true;
-                    const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned int)(k * 64 + lane);
-                    if (kk < key) key = kk;
-                }
-            }
-        }
-    }
-    if (__ballot(anomaly) != 0ull) return trace<true>(sc, r, best);   // a grazing hit at or before its box's entry: the reference's walk decides
-    unsigned long long have = __ballot(key != ~0ull);
-    unsigned long long wkey = ~0ull;
-    const int klo = (int)(unsigned int)key, khi = (int)(unsigned int)(key >> 32);
-    int wprim = -1;
-    while (have != 0ull) {
-        const int l = __ffsll((long long)have) - 1;
-        have &= have - 1ull;
-        const unsigned long long kk = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(khi, l) << 32) |
-                                      (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(klo, l);
-        if (kk < wkey) wkey = kk;
-    }
-    best.inst = -1;
-    if (wkey == ~0ull) { best.t = FLT_MAX; best.prim = -1; return false; }
-    best.t = __uint_as_float((unsigned int)(wkey >> 32));
-    // the winner's sphere: slot and lane from its leaf ordinal
-    const int q = (int)(unsigned int)wkey, wslot = q >> 6, wlane = q & 63;
-#pragma unroll
-    for (int k = 0; k < RT_WAVE_SLOTS; ++k) if (k == wslot) wprim = __builtin_amdgcn_readlane(w.prim[k], wlane);
-    best.prim = wprim;
-    return true;
 }
 
 // aabb::hit for rays whose 1/d components are all finite: identical result to slab_test()

@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(256) rt_render_pixel_kernel(rt_scene_dev sd, r
             col = col + radiance;
         }
         store_pixel(fp, i, lrow, col);
+        if (fp.pixel_cost) fp.pixel_cost[(size_t)lrow * fp.nx + i] = (unsigned int)rays;   // calibration pass: this pixel's rays (the cost prior)
     }
     if (pass_in_lds) {
         __syncthreads();

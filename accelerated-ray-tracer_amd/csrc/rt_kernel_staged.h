@@ -56,6 +56,21 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     // wave-uniform addresses (scalar cache, no LDS), the object kind is a scalar branch, and a lane only carries the index
     // below which it skips (a failed interior box).  Same tests against the same limits in the same order as the walk.
     constexpr bool SCAN = LDS_MODE == 4;
+    // tier sizes of a ranked launch, left in device memory by the ranking kernels (rt_rank.hip); wave-uniform
+    rt_rank_info rk;
+    rk.heavy_items = 0u; rk.heavy_threshold = 0xFFFFFFFFu; rk.tier1_items = 0u; rk.tier2_items = 0u;
+    rk.tier1_wgs = 0; rk.main_skip_wgs = 0; rk.sparse_wgs = 0; rk.sparse_stride = 1; rk.semi_wgs = 0; rk.semi_stride = 1;
+    if (fp.rank) {
+        const rt_rank_info* q = fp.rank;
+        rk.heavy_items = q->heavy_items; rk.heavy_threshold = q->heavy_threshold; rk.tier1_items = q->tier1_items;
+        rk.tier2_items = q->tier2_items; rk.semi_wgs = q->semi_wgs; rk.semi_stride = q->semi_stride;
+        rk.main_skip_wgs = q->main_skip_wgs; rk.sparse_wgs = q->sparse_wgs; rk.sparse_stride = q->sparse_stride;
+    }
+    // Tier 1 of the list -- the dearest pixels, one per wave -- is the tier kernel's (rt_kernel_tier.h), which runs beside
+    // this one.  Where its workgroups do not fit next to a full grid of this kernel (register budgets, rt_device.h) the first
+    // main_skip_wgs workgroups leave at once and their slots are taken by tier workgroups.
+    const int wg = (int)blockIdx.x - rk.main_skip_wgs;
+    if (wg < 0) return;
     const SceneView sc = stage_scene<LDS_MODE>(sd, lds);
     const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
     const int n_nodes = sc.n_nodes;
@@ -75,169 +90,16 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     bool have_pixel = false, first = true, finite_inv = true;
     bool tier3_open = true;      // this lane has not yet seen the end of the tier-3 queue
     unsigned int rays = 0, rays_at_pixel_start = 0;
-    // Sparse mode (see rt_abi.hip, "heavy tiles"): the first fp.sparse_wgs workgroups start by serving the queue of the
-    // few dearest tiles with only every fp.sparse_stride-th lane, because a lane's rays advance ~2.5x faster in a wave
-    // with few live lanes and those pixels' sequential chains bound the frame time.  When that queue is drained and the
-    // wave's own heavy pixels are finished it becomes an ordinary wave.  Wave-uniform.
-    // tier sizes of a ranked launch, left in device memory by the ranking kernels (rt_rank.hip); wave-uniform
-    rt_rank_info rk;
-    rk.heavy_items = 0u; rk.heavy_threshold = 0xFFFFFFFFu; rk.tier0_items = 0u; rk.tier1_items = 0u; rk.tier2_items = 0u;
-    rk.tier0_wgs = 0; rk.tier1_wgs = 0; rk.sparse_wgs = 0; rk.sparse_stride = 1; rk.semi_wgs = 0; rk.semi_stride = 1;
-    if (fp.rank) {
-        const rt_rank_info* q = fp.rank;
-        rk.heavy_items = q->heavy_items; rk.heavy_threshold = q->heavy_threshold; rk.tier0_items = q->tier0_items; rk.tier1_items = q->tier1_items;
-        rk.tier2_items = q->tier2_items; rk.semi_wgs = q->semi_wgs; rk.semi_stride = q->semi_stride;
-        rk.tier0_wgs = q->tier0_wgs; rk.tier1_wgs = q->tier1_wgs; rk.sparse_wgs = q->sparse_wgs; rk.sparse_stride = q->sparse_stride;
-    }
-    bool sparse = (int)blockIdx.x < rk.sparse_wgs;
+    // Sparse mode (see rt_abi.hip, "heavy tiles"): the first sparse_wgs workgroups start by serving tier 2 of the list with
+    // only every sparse_stride-th lane, because a lane's rays advance ~2x faster in a wave with few live lanes and those
+    // pixels' sequential chains bound the frame time.  When that queue is drained and the wave's own heavy pixels are
+    // finished it becomes an ordinary wave.  Wave-uniform.
+    bool sparse = wg < rk.sparse_wgs;
     // "semi" workgroups come next: tier 3 (listed pixels too cheap for a sparse wave) with every semi_stride-th lane live
-    bool semi = !sparse && (int)blockIdx.x < rk.sparse_wgs + rk.semi_wgs;
+    bool semi = !sparse && wg < rk.sparse_wgs + rk.semi_wgs;
 #ifdef RT_DIAG
     const bool diag_was_sparse = sparse;
 #endif
-    // Tier-1 waves hold ONE pixel each -- the dearest pixels of the frame, whose sequential chains bound the frame time.
-    // With a single live lane the state machine below is pure overhead, so they run the reference's plain loop nest
-    // (as kernel A does) on pixels parked by part 1, one after another, and only then join the ordinary waves.
-    // Tier-0 workgroups (spheres-only scenes) go one step further for the very dearest pixels: the whole workgroup holds
-    // ONE pixel and every ray is traced by all its threads at once (trace_group()), which cuts the time per ray -- and
-    // with it the sequential chain that bounds the frame and every multi-GPU partition of it -- several times over.
-    const bool tier0 = SPHERES_ONLY && LDS_MODE == 2 && (int)blockIdx.x < rk.tier0_wgs && fp.state_in != nullptr;   // workgroup-uniform
-    const bool tier1 = sparse && !tier0 && (int)blockIdx.x < rk.tier0_wgs + rk.tier1_wgs && fp.state_in != nullptr;
-#ifdef RT_DIAG
-    const unsigned long long diag_t_start_cycles = __builtin_readcyclecounter();
-#endif
-    if (tier0 || tier1) {
-        __builtin_amdgcn_s_setprio(3);
-        unsigned int* t0_scratch = reinterpret_cast<unsigned int*>(lds + fp.tier0_lds_offset);
-        unsigned long long* t0_slots = reinterpret_cast<unsigned long long*>(t0_scratch + 4);   // [2][16]
-        unsigned int* t0_leaves = t0_scratch + 4 + 64;
-        int t0_n_leaves = 0, t0_parity = 0;
-        // the leaf list (node indices in depth-first order) behind the scene data: tier 0 deals it out one leaf per
-        // thread, tier 1 (spheres-only scenes resident in LDS) one leaf per lane and register slot (trace_wave)
-        const bool wave_leaves_ok = SPHERES_ONLY && LDS_MODE == 2 && fp.tier0_lds_offset != 0u;
-        if (tier0 || wave_leaves_ok) {
-            if (threadIdx.x < 64) {   // one wave: ballots give every leaf its place in order
-                int base = 0;
-                for (int k0 = 0; k0 < n_nodes; k0 += 64) {
-                    const int k = k0 + (int)threadIdx.x;
-                    const bool leaf = k < n_nodes && sc.nodes[k].prim >= 0;
-                    const unsigned long long m = __ballot(leaf);
-                    if (leaf) t0_leaves[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = (unsigned int)k;
-                    base += __popcll(m);
-                }
-                if (threadIdx.x == 0) t0_scratch[0] = (unsigned int)base;
-                // trace_wave's slot unions (rt_device_funcs.h): box of leaves 64 k .. 64 k + 63, behind the leaf list where
-                // the scratch has room for them (it is sized for one entry per node; the interior nodes' entries are free)
-                const bool room = (n_nodes - base) * 4 >= RT_WAVE_SLOTS * 32 && base <= 64 * RT_WAVE_SLOTS;
-                if (threadIdx.x == 0) t0_scratch[2] = room ? 1u : 0u;
-                if (room) {
-                    float* ranges = reinterpret_cast<float*>(t0_leaves + base);
-                    for (int k = 0; k < RT_WAVE_SLOTS; ++k) {
-                        const int q = k * 64 + (int)threadIdx.x;
-                        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-                        if (q < base) {
-                            const rt_node nd = sc.nodes[t0_leaves[q]];
-                            for (int a = 0; a < 3; ++a) { lo[a] = nd.bmin[a]; hi[a] = nd.bmax[a]; }
-                        }
-                        for (int a = 0; a < 3; ++a)
-                            for (int off = 32; off > 0; off >>= 1) {
-                                lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
-                                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
-                            }
-                        if (threadIdx.x == 0) { for (int a = 0; a < 3; ++a) { ranges[k * 8 + a] = lo[a]; ranges[k * 8 + 3 + a] = hi[a]; } ranges[k * 8 + 6] = 0.f; ranges[k * 8 + 7] = 0.f; }
-                    }
-                }
-            }
-            __syncthreads();
-            t0_n_leaves = (int)t0_scratch[0];
-        }
-        const bool tier1_wave = tier1 && wave_leaves_ok && t0_n_leaves <= 64 * RT_WAVE_SLOTS;   // workgroup-uniform
-        // every lane of the wave (tier 1) / thread of the workgroup (tier 0) carries the same pixel and computes the same
-        // values; only the traversal is shared out
-        auto tier_pixels = [&](auto trace_ray) {
-        for (;;) {
-            uint32_t idx = 0;
-            if (tier0) {
-                if (threadIdx.x == 0) t0_scratch[1] = atomicAdd(fp.work_counter + 3, 1u);
-                __syncthreads();
-                idx = t0_scratch[1];
-                __syncthreads();
-                if (idx >= rk.tier0_items) break;
-            } else {
-                if ((threadIdx.x & 63) == 0) idx = atomicAdd(fp.work_counter + 2, 1u);
-                idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-                if (idx >= rk.tier1_items) break;
-                idx += rk.tier0_items;
-            }
-            const uint32_t pix = fp.heavy_pixels[idx];
-            const int lrow = (int)(pix / (uint32_t)fp.nx), i = (int)(pix - (uint32_t)lrow * (uint32_t)fp.nx);
-            const int j = local_to_global_row(fp, lrow);
-            const rt_pixel_state st = fp.state_in[pix];
-            rt_xorwow pg;
-            pg.v0 = st.rng[0]; pg.v1 = st.rng[1]; pg.v2 = st.rng[2]; pg.v3 = st.rng[3]; pg.v4 = st.rng[4]; pg.d = st.rng[5];
-            f3 pcol = mk3(st.col[0], st.col[1], st.col[2]);
-            unsigned int pixel_rays = 0;
-            for (int sidx = fp.sample_begin; sidx < fp.sample_end; ++sidx) {                 // main.cu:119-125
-                const float u = ((float)i + rt_xorwow_uniform(pg)) / (float)fp.nx;
-                const float v = ((float)j + rt_xorwow_uniform(pg)) / (float)fp.ny;
-                Ray r = camera_get_ray(sd.camera, u, v, pg);
-                f3 thr = mk3(1, 1, 1), rad = mk3(0, 0, 0);
-                for (int depth = 0; depth < 50; ++depth) {                                   // main.cu:54-84
-                    HitInfo h;
-                    ++pixel_rays;
-#ifdef RT_DIAG
-                    const unsigned long long dg0 = __builtin_readcyclecounter();
-#endif
-                    const bool hit = trace_ray(r, h);
-#ifdef RT_DIAG
-                    const unsigned long long dg1 = __builtin_readcyclecounter();
-                    if (threadIdx.x == 0) { diag_local[15] += 1; diag_local[14] += dg1 - dg0; }   // slots 14/15: tier loops only
-#endif
-                    if (!hit) { rad = fma3(thr, miss_color(fp, r), rad); break; }
-                    const HitRec rec = resolve_hit<SPHERES_ONLY, NEED_UV>(sc, r, h);
-                    f3 emitted, attenuation;
-                    Ray scattered;
-                    const bool go_on = shade<TEX>(sc, r, rec, pg, emitted, attenuation, scattered);
-#ifdef RT_DIAG
-                    if (threadIdx.x == 0) diag_shade_cycles += __builtin_readcyclecounter() - dg1;   // resolve + shade, tier loops
-#endif
-
-                    rad = fma3(thr, emitted, rad);
-                    if (!go_on) break;
-                    thr = thr * attenuation;
-                    r = scattered;
-                }
-                pcol = pcol + rad;
-            }
-            if (tier0 ? threadIdx.x == 0 : (threadIdx.x & 63) == 0) {
-                if (fp.state_out) {   // a middle part of a split frame: park the pixel again
-                    rt_pixel_state so;
-                    so.rng[0] = pg.v0; so.rng[1] = pg.v1; so.rng[2] = pg.v2; so.rng[3] = pg.v3; so.rng[4] = pg.v4; so.rng[5] = pg.d;
-                    so.col[0] = pcol.x; so.col[1] = pcol.y; so.col[2] = pcol.z; so.cost = fp.state_in[pix].cost + pixel_rays;   // (bit 31, "listed", stays: this launch's tile queue must keep skipping the pixel)
-                    fp.state_out[pix] = so;
-                    atomicAdd(&fp.tile_cost[(lrow >> 3) * fp.tiles_x + (i >> 3)], pixel_rays);
-                } else {
-                    store_pixel(fp, i, lrow, pcol);
-                }
-                rays += pixel_rays;
-            }
-        }
-        };
-        // three copies of the loop, one per traversal routine, so that the register image of trace_wave()'s leaf boxes is
-        // live only where it is used
-        if (SPHERES_ONLY && tier0) tier_pixels([&](const Ray& r, HitInfo& h) { return trace_group(sc, r, h, t0_leaves, t0_n_leaves, t0_slots, t0_parity); });
-        else if (SPHERES_ONLY && tier1_wave) {
-            WaveLeaves wl;
-            wave_leaves_load(sc, t0_leaves, t0_n_leaves, wl);
-            const float* slot_ranges = t0_scratch[2] ? reinterpret_cast<const float*>(t0_leaves + t0_n_leaves) : nullptr;   // workgroup-uniform
-            tier_pixels([&](const Ray& r, HitInfo& h) { return trace_wave(sc, r, h, wl, t0_n_leaves, slot_ranges); });
-        } else tier_pixels([&](const Ray& r, HitInfo& h) { return trace_wide<SPHERES_ONLY>(sc, r, h); });
-        __builtin_amdgcn_s_setprio(0);
-#ifdef RT_DIAG
-        if (threadIdx.x == 0) atomicAdd(fp.ray_counter + 26, (unsigned long long)(__builtin_readcyclecounter() - diag_t_start_cycles));   // whole tier loop of this wave
-#endif
-        sparse = false;   // queue drained: this wave / workgroup becomes ordinary
-    }
     // A sparse wave's few lanes are on the frame's critical path: let it win instruction-issue arbitration against the
     // three ordinary waves sharing its SIMD (priority outranks age, MI355X_MICROARCH.md "Two waves per SIMD").
     if (sparse && fp.sparse_priority > 0) {
@@ -509,7 +371,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                             rt_pixel_state st;
                             st.rng[0] = g.v0; st.rng[1] = g.v1; st.rng[2] = g.v2; st.rng[3] = g.v3; st.rng[4] = g.v4; st.rng[5] = g.d;
                             st.col[0] = col.x; st.col[1] = col.y; st.col[2] = col.z;
-                            st.cost = c + (fp.state_in ? fp.state_in[at].cost : 0u);   // a middle part adds to what the pixel cost before (bit 31, "listed", stays)   // a middle part adds to what the pixel cost before
+                            st.cost = c + (fp.state_in ? (fp.fresh ? (fp.state_in[at].cost & 0x80000000u) : fp.state_in[at].cost) : 0u);   // a middle part adds to what the pixel cost before; bit 31 ("listed") stays; a fresh part drops the prior
                             fp.state_out[at] = st;
                             atomicAdd(&fp.tile_cost[(px_lrow >> 3) * fp.tiles_x + (px_i >> 3)], c);
                         } else {
@@ -520,12 +382,11 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                     while (!have_pixel && alive) {
                         bool ok;
                         if (sparse) {
-                            // heavy list (sorted by descending cost): tier 1 = its first tier1_items entries
-                            // tier 2 of the heavy list (tier 1 is served by the plain loop at the top of the kernel)
+                            // tier 2 of the heavy list (sorted by descending cost; its first tier1_items entries are the tier kernel's)
                             if (((threadIdx.x & 63) % (unsigned)rk.sparse_stride) != 0u) { alive = false; break; }
                             const uint32_t k2 = atomicAdd(fp.work_counter + 1, 1u);
                             if (k2 >= rk.tier2_items) { alive = false; break; }
-                            const uint32_t at = rk.tier0_items + rk.tier1_items + k2;
+                            const uint32_t at = rk.tier1_items + k2;
                             const uint32_t pix = fp.heavy_pixels[at];
                             px_lrow = (int)(pix / (uint32_t)fp.nx); px_i = (int)(pix - (uint32_t)px_lrow * (uint32_t)fp.nx);
                             ok = true;
@@ -534,7 +395,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                             // workgroups' live lanes, or (no semi workgroups) on any ordinary lane before it takes a tile
                             if (semi && ((threadIdx.x & 63) % (unsigned)rk.semi_stride) != 0u) { alive = false; break; }
                             const uint32_t k3 = atomicAdd(fp.work_counter + 4, 1u);
-                            const uint32_t first3 = rk.tier0_items + rk.tier1_items + rk.tier2_items;
+                            const uint32_t first3 = rk.tier1_items + rk.tier2_items;
                             if (first3 + k3 >= rk.heavy_items) { tier3_open = false; if (semi) { alive = false; break; } continue; }
                             const uint32_t pix = fp.heavy_pixels[first3 + k3];
                             px_lrow = (int)(pix / (uint32_t)fp.nx); px_i = (int)(pix - (uint32_t)px_lrow * (uint32_t)fp.nx);
@@ -552,7 +413,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                             diag_last_src = sparse ? 2u : (tier3_open ? 3u : 0u);
 #endif
                             px_j = local_to_global_row(fp, px_lrow);
-                            if (fp.state_in) {   // second part of a split frame: pick the pixel up where the first part left it
+                            if (fp.state_in && !fp.fresh) {   // a later part of a split frame: pick the pixel up where the previous part left it
                                 const rt_pixel_state st = fp.state_in[(size_t)px_lrow * fp.nx + px_i];
                                 g.v0 = st.rng[0]; g.v1 = st.rng[1]; g.v2 = st.rng[2]; g.v3 = st.rng[3]; g.v4 = st.rng[4]; g.d = st.rng[5];
                                 col = mk3(st.col[0], st.col[1], st.col[2]);

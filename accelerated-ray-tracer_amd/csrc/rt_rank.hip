@@ -77,9 +77,8 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_tiles_kernel(rt_rank_par
         // cost thresholds of the heavy list and its tiers, from the mean cost per pixel so far
         const double mean = (double)*rp.ray_counter / (double)rp.n_pixels;
         rt_rank_info inf;
-        inf.heavy_items = 0u; inf.heavy_threshold = 0xFFFFFFFFu; inf.tier0_items = 0u; inf.tier1_items = 0u; inf.tier2_items = 0u;
-        inf.tier0_wgs = 0; inf.tier1_wgs = 0; inf.sparse_wgs = 0; inf.sparse_stride = 1; inf.semi_wgs = 0; inf.semi_stride = 1;
-        inf.threshold0 = (unsigned int)(mean * (double)rp.tier0_factor + 0.999);
+        inf.heavy_items = 0u; inf.heavy_threshold = 0xFFFFFFFFu; inf.tier1_items = 0u; inf.tier2_items = 0u;
+        inf.tier1_wgs = 0; inf.main_skip_wgs = 0; inf.sparse_wgs = 0; inf.sparse_stride = 1; inf.semi_wgs = 0; inf.semi_stride = 1;
         inf.threshold1 = (unsigned int)(mean * (double)rp.tier1_factor + 0.999);
         inf.threshold2 = (unsigned int)(mean * (double)rp.sparse_factor + 0.999);
         inf.collected = 0u;
@@ -121,7 +120,7 @@ __global__ void rt_collect_heavy_kernel(rt_rank_params rp) {
 __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_params rp) {
     __shared__ unsigned int hist[RANK_BUCKETS + 1];
     __shared__ unsigned int scratch;
-    __shared__ unsigned int n_tier0, n_tier1, n_tier2, sort_hi;
+    __shared__ unsigned int n_tier1, n_tier2, sort_hi;
     __shared__ unsigned long long sort_span;
     rt_rank_info inf = *rp.info;
     const unsigned int count = inf.collected;
@@ -134,16 +133,14 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
     const unsigned long long* list = rp.heavy_list;
     wg_bucket_sort_desc(count, [list](unsigned int i) { return (unsigned int)(list[i] >> 32); },
                         [list](unsigned int i) { return (unsigned int)(list[i] & 0xFFFFFFFFull); }, rp.heavy_pixels, hist, &scratch, &sort_hi, &sort_span);
-    if (threadIdx.x == 0) { n_tier0 = 0u; n_tier1 = 0u; n_tier2 = 0u; }
+    if (threadIdx.x == 0) { n_tier1 = 0u; n_tier2 = 0u; }
     __syncthreads();
-    unsigned int c0 = 0u, c1 = 0u, c2 = 0u;
+    unsigned int c1 = 0u, c2 = 0u;
     for (unsigned int i = threadIdx.x; i < count; i += blockDim.x) {
         const unsigned int c = (unsigned int)(list[i] >> 32);
-        c0 += c >= inf.threshold0 ? 1u : 0u;
         c1 += c >= inf.threshold1 ? 1u : 0u;
         c2 += c >= inf.threshold2 ? 1u : 0u;
     }
-    if (c0) atomicAdd(&n_tier0, c0);
     if (c1) atomicAdd(&n_tier1, c1);
     if (c2) atomicAdd(&n_tier2, c2);
     __syncthreads();
@@ -166,38 +163,35 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
             if (work > budget) break;
             admitted = upto;
         }
-        if (n_tier0 > admitted) n_tier0 = admitted;
         if (n_tier1 > admitted) n_tier1 = admitted;
         if (n_tier2 > admitted) n_tier2 = admitted;
     }
-    // ---- workgroups per tier.  tier 0 = one pixel per workgroup at a time, tier 1 = one per wave, tier 2 = 64 /
-    // sparse_stride live lanes per wave; each queue is served dearest first and whatever exceeds its workgroups waits.
+    // ---- workgroups per tier.  Tier 1 = the tier kernel's (one pixel per wave at a time, workgroups of four waves), tier 2 =
+    // 64 / sparse_stride live lanes per wave of the main kernel; each queue is served dearest first and whatever exceeds its
+    // workgroups waits.
     const unsigned int cap_wgs = rp.max_grid * (unsigned int)rp.sparse_percent / 100u;
-    unsigned int tier0_items = rp.tier0_possible ? n_tier0 : 0u, tier1_items = n_tier1;
-    if (tier0_items > (unsigned int)rp.tier0_pixels) tier0_items = (unsigned int)rp.tier0_pixels;
-    if (tier0_items > cap_wgs / 2u) tier0_items = cap_wgs / 2u;
-    const unsigned int tier0_wgs = tier0_items;
-    tier1_items = tier1_items > tier0_items ? tier1_items - tier0_items : 0u;            // tier 1 follows tier 0 in the list
+    unsigned int tier1_items = rp.tier_possible ? n_tier1 : 0u;
     if (tier1_items > (unsigned int)rp.tier1_pixels) tier1_items = (unsigned int)rp.tier1_pixels;
     // a tier-1 wave takes its pixels one after the other from the tier's queue (dearest first): tier1_depth of them on
-    // average, fewer workgroups than that only if the sparse share of the grid is used up
+    // average, fewer workgroups than that only if the tier kernel's grid is used up
     const unsigned int depth1 = rp.tier1_depth > 0 ? (unsigned int)rp.tier1_depth : 1u;
-    unsigned int tier1_wgs = (tier1_items + rp.waves_per_wg * depth1 - 1u) / (rp.waves_per_wg * depth1);
-    if (tier0_wgs + tier1_wgs > cap_wgs / 2u + tier0_wgs / 2u) tier1_wgs = cap_wgs / 2u > tier0_wgs / 2u ? cap_wgs / 2u - tier0_wgs / 2u : 0u;
+    const unsigned int tier_waves_per_wg = RT_TIER_THREADS / 64u;
+    unsigned int tier1_wgs = (tier1_items + tier_waves_per_wg * depth1 - 1u) / (tier_waves_per_wg * depth1);
+    if (tier1_wgs > (unsigned int)rp.tier_wgs_cap) tier1_wgs = (unsigned int)rp.tier_wgs_cap;
     if (tier1_wgs == 0u) tier1_items = 0u;
     // tier 2 = what is left of the pixels at or above the sparse threshold; tier 3 = the rest of the list
-    unsigned int tier2_items = n_tier2 > tier0_items + tier1_items ? n_tier2 - tier0_items - tier1_items : 0u;
-    if (tier0_items + tier1_items + tier2_items > count) tier2_items = count - tier0_items - tier1_items;
+    unsigned int tier2_items = n_tier2 > tier1_items ? n_tier2 - tier1_items : 0u;
+    if (tier1_items + tier2_items > count) tier2_items = count - tier1_items;
     const unsigned int per_wg2 = rp.waves_per_wg * (64u / (unsigned int)rp.sparse_stride);
     unsigned int tier2_wgs = (tier2_items + per_wg2 - 1u) / per_wg2;
-    if (tier0_wgs + tier1_wgs + tier2_wgs > cap_wgs) tier2_wgs = cap_wgs > tier0_wgs + tier1_wgs ? cap_wgs - tier0_wgs - tier1_wgs : 0u;
+    if (tier2_wgs > cap_wgs) tier2_wgs = cap_wgs;
     if (tier2_items > tier2_wgs * per_wg2) tier2_items = tier2_wgs * per_wg2;   // what the sparse workgroups cannot hold at once joins tier 3
-    const unsigned int sparse_wgs = tier0_wgs + tier1_wgs + tier2_wgs;
+    const unsigned int sparse_wgs = tier2_wgs;
     // tier 3 on workgroups of their own with every semi_stride-th lane live (a lane's rays advance faster the fewer lanes
     // its wave has), as many as hold the whole tier at once
     unsigned int semi_wgs = 0u;
     if (rp.semi_stride > 0) {
-        const unsigned int tier3_items = count - tier0_items - tier1_items - tier2_items;
+        const unsigned int tier3_items = count - tier1_items - tier2_items;
         const unsigned int per_wg3 = rp.waves_per_wg * (64u / (unsigned int)rp.semi_stride);
         semi_wgs = (tier3_items + per_wg3 - 1u) / per_wg3;
         const unsigned int room = cap_wgs > sparse_wgs ? cap_wgs - sparse_wgs : 0u;
@@ -205,10 +199,20 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
     }
     unsigned int total = rp.normal_need + sparse_wgs + semi_wgs;
     if (total > rp.max_grid) total = rp.max_grid;
+    // Where a tier workgroup does not fit beside a full main grid (tier_waves_per_main_wg > 0: that many tier waves fit into
+    // the slot of one main workgroup), main workgroups make room: as many as the tier kernel's waves need beyond the slots
+    // the main grid leaves empty anyway.
+    unsigned int skip = 0u;
+    if (rp.tier_waves_per_main_wg > 0 && tier1_wgs > 0u) {
+        const unsigned int slots = (tier1_wgs * tier_waves_per_wg + (unsigned int)rp.tier_waves_per_main_wg - 1u) / (unsigned int)rp.tier_waves_per_main_wg;
+        const unsigned int spare = rp.max_grid > total ? rp.max_grid - total : 0u;
+        skip = slots > spare ? slots - spare : 0u;
+        if (skip + 1u > total) skip = total > 1u ? total - 1u : 0u;   // at least one main workgroup keeps working
+    }
     if (total > sparse_wgs + semi_wgs) {
         inf.semi_wgs = (int32_t)semi_wgs; inf.semi_stride = rp.semi_stride > 0 ? rp.semi_stride : 1;
-        inf.heavy_items = count; inf.tier0_items = tier0_items; inf.tier1_items = tier1_items; inf.tier2_items = tier2_items;
-        inf.tier0_wgs = (int32_t)tier0_wgs; inf.tier1_wgs = (int32_t)tier1_wgs; inf.sparse_wgs = (int32_t)sparse_wgs;
+        inf.heavy_items = count; inf.tier1_items = tier1_items; inf.tier2_items = tier2_items;
+        inf.tier1_wgs = (int32_t)tier1_wgs; inf.main_skip_wgs = (int32_t)skip; inf.sparse_wgs = (int32_t)sparse_wgs;
         inf.sparse_stride = rp.sparse_stride;
     } else {
         inf.heavy_items = 0u; inf.heavy_threshold = 0xFFFFFFFFu;
@@ -216,7 +220,43 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
     *rp.info = inf;
 }
 
+// The cost prior of a ranked FIRST part: before a single sample of the frame is rendered, every pixel gets the rays its place
+// in the scene's calibration frame cost (rt_scene_create traces a small frame through the scene's own camera and keeps
+// the per-pixel ray counts), the maximum over the 3 x 3 calibration pixels around it -- dear regions (glass, the inside
+// of a medium) are contiguous, their edges are not where a 256-pixel-wide frame puts them.  The ranking then lists and
+// tiers the pixels exactly as it does from measured costs, so that the dearest chains start on tier waves at sample 0
+// instead of running the first part at an ordinary lane's pace.  Scheduling only.
+__global__ void rt_prior_kernel(rt_prior_params pp) {
+    const unsigned int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int n = (unsigned int)pp.local_rows * (unsigned int)pp.nx;
+    unsigned int est = 0u;
+    if (p < n) {
+        const int lrow = (int)(p / (unsigned int)pp.nx), i = (int)(p - (unsigned int)lrow * (unsigned int)pp.nx);
+        const int t = lrow / pp.tile_rows;
+        const int j = (pp.tile_first + t * pp.tile_stride) * pp.tile_rows + (lrow - t * pp.tile_rows);
+        const int ci = min(pp.cal_nx - 1, (int)(((long long)i * pp.cal_nx) / pp.nx)), cj = min(pp.cal_ny - 1, (int)(((long long)j * pp.cal_ny) / pp.ny));
+        for (int dj = -1; dj <= 1; ++dj)
+            for (int di = -1; di <= 1; ++di) {
+                const int x = ci + di, y = cj + dj;
+                if (x < 0 || y < 0 || x >= pp.cal_nx || y >= pp.cal_ny) continue;
+                const unsigned int c = pp.cal_cost[(size_t)y * pp.cal_nx + x];
+                est = c > est ? c : est;
+            }
+        pp.state[p].cost = est;
+        atomicAdd(&pp.tile_cost[(lrow >> 3) * pp.tiles_x + (i >> 3)], est);
+    }
+    unsigned long long sum = est;
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(pp.total, sum);
+}
+
 }  // namespace
+
+hipError_t rt_launch_prior(const rt_prior_params& pp, hipStream_t st) {
+    const unsigned int n = (unsigned int)pp.local_rows * (unsigned int)pp.nx;
+    hipLaunchKernelGGL(rt_prior_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, pp);
+    return hipGetLastError();
+}
 
 hipError_t rt_launch_rank(const rt_rank_params& rp, hipStream_t st) {
     hipLaunchKernelGGL(rt_rank_tiles_kernel, dim3(1), dim3(RANK_THREADS), 0, st, rp);

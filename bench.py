@@ -148,6 +148,30 @@ def gather_rows(local, plan: "RowPlan", rank: int, world: int, dev):
     return full
 
 
+def multi_gpu_report(per_rank, ms_per_step: float, args, world: int) -> dict:
+    """Per-rank render-kernel time, gather time and rays of an N > 1 run, and the strong-scaling efficiency T1 / (N * T_N)
+    against the committed one-GPU line of the same workload (profiles/r*_bench_n1.json, the newest by name)."""
+    import glob
+    k = [p[0] for p in per_rank]; g = [p[1] for p in per_rank]; r = [p[2] for p in per_rank]
+    rep = {"kernel_ms_min": round(min(k), 3), "kernel_ms_max": round(max(k), 3), "kernel_ms_per_rank": [round(x, 3) for x in k],
+           "gather_ms_rank0": round(g[0], 3), "gather_ms_max": round(max(g), 3),
+           "rays_per_rank_min": int(min(r)), "rays_per_rank_max": int(max(r)),
+           "note": "kernel_ms = HIP-event time of a rank's own render launches; gather_ms = the RCCL gather + un-interleave on the same stream, which on rank 0 includes waiting for the slowest rank"}
+    t1, src = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")), reverse=True):
+        try:
+            rec = json.loads(open(path).read().strip().splitlines()[-1])
+        except Exception:
+            continue
+        wl = rec.get("config", {}).get("workload", "")
+        if rec.get("n_gpus") == 1 and f"{args.nx}x{args.ny} @ {args.ns} spp" in wl and args.scene.split("_")[0] in wl:
+            t1, src = float(rec["ms_per_step"]), os.path.relpath(path, ROOT)
+            break
+    if t1 is not None:
+        rep.update({"t1_ms": t1, "t1_source": src, "efficiency_t1_over_n_tn": round(t1 / (world * ms_per_step), 4)})
+    return rep
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,35 +215,34 @@ def host_cores() -> int:
 
 
 def cpu_baseline(scene_name: str, nx: int, ny: int, ns: int) -> dict:
-    """The oracle (a port of the reference's algorithm, see oracle/) timed on this box's host cores."""
+    """The oracle (a port of the reference's algorithm, see oracle/) timed on this box's host cores.  One fixed, stated
+    configuration: one thread per usable core (affinity mask cut down to the cgroup CPU quota), no probing; the sample is
+    the bench frame at reduced spp, doubled until it is at least 3 s of wall time."""
     import oracle
     name = "bouncing" if scene_name == "random_scene" else scene_name
     sc = oracle.OracleScene(name, nx, ny)
-    # all the host cores this job may use; where the box only grants a share of a larger machine without saying so
-    # (no cgroup quota to read), fewer threads than logical cpus can be faster, so a 2-spp probe picks among a few counts
-    cores = host_cores()
-    best_t, best_rate = cores, 0.0
+    threads = host_cores()
     try:
         logical = len(os.sched_getaffinity(0))
     except AttributeError:
-        logical = os.cpu_count() or cores
-    # (a quota of Q cpus is CPU time, not a thread limit: on these boxes 2-4 threads per quota cpu measured faster)
-    for t in sorted({min(logical, 4 * cores), min(logical, 2 * cores), cores, max(1, cores // 2)}, reverse=True):
+        logical = os.cpu_count() or threads
+    sc.render(1, threads=threads, counters=True)   # page the library and the scene in; not timed
+    while True:
         t0 = time.time()
-        _, c = sc.render(4, threads=t, counters=True)
-        rate = c["rays"] / (time.time() - t0)
-        if rate > best_rate * 1.05:
-            best_t, best_rate = t, rate
-    threads = best_t
-    t0 = time.time()
-    _, cnt = sc.render(ns, threads=threads, counters=True)
-    dt = time.time() - t0
+        _, cnt = sc.render(ns, threads=threads, counters=True)
+        dt = time.time() - t0
+        if dt >= 3.0 or ns >= 1024:
+            break
+        ns *= 2
     return {"value": round(cnt["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{scene_name} {nx}x{ny} @ {ns} spp (same scene/seeds, reduced spp), {cnt['rays']} rays in {dt:.1f} s on {threads} threads (os.cpu_count() = {os.cpu_count()}, usable per affinity / cgroup quota = {cores})"}
+            "sample": f"{scene_name} {nx}x{ny} @ {ns} spp (same scene/seeds, reduced spp), {cnt['rays']} rays in {dt:.1f} s on {threads} threads = usable cores (cgroup quota / affinity; {logical} logical cpus in the affinity mask, os.cpu_count() = {os.cpu_count()})"}
 
 
 def main():
     args = parse()
+    # before anything initialises the GPU runtime: the host driver of these boxes only supports dmabuf IPC (RCCL,
+    # cross-process device memory); the image exports this already, a bare environment would not
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import accelerated_ray_tracer_amd as art
@@ -240,7 +263,6 @@ def main():
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -265,17 +287,23 @@ def main():
     full = None
 
     stream = torch.cuda.current_stream().cuda_stream
-    kernel_ms, rays_step = [], 0
+    kernel_ms, gather_ms, rays_step = [], [], 0
+    ev_g0, ev_g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # same stream as the render and the gather
 
     def step(record: bool):
         nonlocal rays_step, full
         _, st = ds.render(frame, out=local.data_ptr(), stream=stream, blocking=False)
         if world > 1:
+            ev_g0.record()
             full = gather_rows(local, plan, rank, world, dev)
+            ev_g1.record()
         st = ds.finish()   # waits for this rank's kernel; HIP-event duration on the launch stream
         if record:
             kernel_ms.append(st.ms_render)
             rays_step = st.rays
+            if world > 1:
+                ev_g1.synchronize()
+                gather_ms.append(ev_g0.elapsed_time(ev_g1))   # includes waiting for the slowest rank's rows
         return st
 
     for _ in range(args.warmup):
@@ -299,6 +327,12 @@ def main():
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     total_rays = float(r.item())
+    per_rank = None
+    if world > 1:   # every rank's own kernel time and gather time, so that a scaling run explains itself
+        mine = torch.tensor([float(np.mean(kernel_ms)), float(np.mean(gather_ms)), float(rays_step)], dtype=torch.float64, device=red_dev)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        per_rank = [[float(x) for x in g.tolist()] for g in got]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -315,6 +349,8 @@ def main():
                        "tile_rows": TILE_ROWS if world > 1 else args.ny},
             "roofline": roofline(args.scene, args.nx, args.ny, args.ns, rays_step, kms, total_rays),
         }
+        if per_rank is not None:
+            line["multi_gpu"] = multi_gpu_report(per_rank, ms_per_step, args, world)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.scene, args.nx, args.ny, args.cpu_ns)
         print(json.dumps(line), flush=True)

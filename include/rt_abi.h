@@ -238,8 +238,12 @@ rt_status rt_frame_finish(rt_scene* scene, rt_stats* stats);
  * and a small kernel puts them into the reference's frame layout.  `f` describes the WHOLE frame (its tile_* fields
  * are ignored); fb receives nx*ny*3 floats (host memory, or memory of device 0 when fb_on_device != 0).  The call
  * returns when the frame is complete.  stats: rays / samples summed over the devices, ms_render = host wall time of
- * the call, reserved = the slowest device's own render time in microseconds.  Pixels are bit-identical to rt_render's
- * on one device: no ray crosses a device and the per-pixel seed is seed_base + the global pixel index. */
+ * the frame (render on every device + gather + reassembly + copy; buffer allocation and communicator set-up of a first
+ * call excluded), reserved = the slowest device's own render time in microseconds.  By construction pixels are
+ * bit-identical to rt_render's on one device -- no ray crosses a device and the per-pixel seed is seed_base + the
+ * global pixel index; on one GPU that is tested for every rank's share and for the reassembly at world sizes 2..8
+ * (tests/test_gpu_parity.py), with N > 1 devices it is UNVERIFIED ON HARDWARE so far.  On any failure after the frames
+ * were enqueued every device is drained (streams synchronised, pending frames closed) before the error is returned. */
 typedef struct rt_multi rt_multi;
 rt_status rt_init_devices(int n_gpus);
 rt_status rt_multi_create(const rt_scene_desc* desc, int n_gpus, rt_multi** out);
@@ -249,6 +253,11 @@ int32_t rt_multi_device_count(const rt_multi* m);
 /* the row partition rt_multi_render uses: which device renders global row j and at which row of its compact buffer
  * (the inverse of rt_local_to_global_row for tile_first = device, tile_stride = n_gpus) */
 rt_status rt_multi_row_owner(int32_t global_row, int32_t tile_rows, int32_t n_gpus, int32_t* device, int32_t* local_row);
+/* diagnostics of the multi-GPU path (tests): load RCCL exactly as rt_multi_render would (`library_name` = that name only,
+ * null = the usual search) -- a missing library is RT_ERR_HIP with the loader's message, no device needed; and the
+ * reassembly step on caller-supplied device buffers, staging[world][max_rows][nx*3] -> frame[ny][nx*3], synchronous. */
+rt_status rt_multi_probe_rccl(const char* library_name);
+rt_status rt_multi_debug_uninterleave(const float* staging, float* frame, int32_t nx, int32_t ny, int32_t tile_rows, int32_t world, int32_t max_rows);
 
 /* Tuning knobs (for A/B measurements; defaults are what ships).  Unknown keys
  * return RT_ERR_INVALID.  The knobs are process-wide; rt_reset_options()

@@ -95,14 +95,20 @@ inline float axis_of(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); 
 
 // correctly rounded binary32 transcendentals (see header)
 inline float cr_powf(float x, float y) { return (float)pow((double)x, (double)y); }
-// Diagnostics (tools/medium_ulp_experiment.py, never a parity test): ORC_LOG_ULP=N moves the result by one ulp for the inputs
-// whose bit pattern is a multiple of N -- a stand-in for a logf that is not correctly rounded in a fraction of its inputs.
+#ifdef ORC_DIAG
+// Diagnostic build only (make librt_oracle_diag.so; tools/medium_ulp_experiment.py loads that library explicitly, no test
+// and no bench ever does): ORC_LOG_ULP=N moves the result by one ulp for the inputs whose bit pattern is a multiple of N --
+// a stand-in for a logf that is not correctly rounded in a fraction of its inputs.  The checker proper (librt_oracle.so)
+// does not contain this code, so no environment variable can change it.
 static const int g_log_ulp_every = [] { const char* e = getenv("ORC_LOG_ULP"); return e ? atoi(e) : 0; }();
 inline float cr_logf(float x) {
     const float v = (float)log((double)x);
     if (g_log_ulp_every > 0) { uint32_t b; memcpy(&b, &x, 4); if (b % (uint32_t)g_log_ulp_every == 0u) return nextafterf(v, INFINITY); }
     return v;
 }
+#else
+inline float cr_logf(float x) { return (float)log((double)x); }
+#endif
 inline float cr_sinf(float x) { return (float)sin((double)x); }
 inline float cr_acosf(float x) { return (float)acos((double)x); }
 inline float cr_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
@@ -1029,13 +1035,23 @@ inline float apply_gamma(float c, float gamma) {                                
     return cr_powf(fmaxf(c, 0.0f), inv);
 }
 
+// Diagnostics for tools/order_experiment.py (never a parity test, never changes a result): every g_ray_stride-th ray of a
+// single-threaded render is appended as (origin, direction, time, t of its closest hit or FLT_MAX), 8 floats.
+unsigned long long g_ray_stride = 0, g_ray_seen = 0;
+std::vector<float>* g_ray_out = nullptr;
+
 V3 path_color(const Scene& S, const Ray& r0, V3 background, bool gradient, Rng& g) { // main.cu:44-87
     Ray cur = r0;
     V3 throughput = v3(1, 1, 1), radiance = v3(0, 0, 0);
     for (int bounce = 0; bounce < 50; ++bounce) {
         Hit rec;
         if (g_cnt) g_cnt->rays++;
-        if (!obj_hit(S.world, cur, 0.001f, FLT_MAX, rec)) {
+        const bool hit_any = obj_hit(S.world, cur, 0.001f, FLT_MAX, rec);
+        if (g_ray_out && g_ray_stride && (g_ray_seen++ % g_ray_stride) == 0) {
+            const float v[8] = {cur.o.x, cur.o.y, cur.o.z, cur.d.x, cur.d.y, cur.d.z, (float)cur.tm, hit_any ? (float)rec.t : FLT_MAX};
+            g_ray_out->insert(g_ray_out->end(), v, v + 8);
+        }
+        if (!hit_any) {
             V3 bg = background;
             if (gradient) {
                 V3 ud = vunit(cur.d);
@@ -1187,7 +1203,8 @@ int orc_dump_nodes(int h, float* out, int cap_nodes) {
     return n;
 }
 
-// Diagnostics for tools/ (never used by a parity test): per-node count of box tests that passed since the last reset, in
+// Per-node count of box tests that passed since the last reset (tools/, and tests/test_gpu_parity.py's check that the
+// device's calibration pass counts what the oracle counts; it never decides a pixel), in
 // the DFS pre-order of orc_dump_nodes.  enable != 0 switches the counting on and clears the counters.
 static void node_pass_rec(const Obj* n, std::vector<unsigned long long>* out, bool clear) {
     if (out) out->push_back(n->stat_pass);
@@ -1203,6 +1220,21 @@ int orc_node_passes(int h, unsigned long long* out, int cap) {
 
 // scene census: out[0..] = list size, spheres, moving spheres, quads(in list), boxes, instances(translate), media,
 // lambertian, metal, dielectric, light (materials of list spheres only), bvh depth
+// Diagnostics (tools/order_experiment.py): render rows [row0, row1) at ns spp on ONE thread and return up to `cap` rays,
+// every stride-th one, as 8 floats each (origin, direction, time, closest t or FLT_MAX).  Returns the number of rays written.
+int orc_ray_sample(int h, int nx, int ny, int ns, int row0, int row1, unsigned long long stride, float* out, int cap) {
+    std::vector<float> rays;
+    g_ray_out = &rays; g_ray_stride = stride ? stride : 1; g_ray_seen = 0;
+    const Scene& S = *g_scenes[h];
+    for (int j = row0; j < row1; ++j)
+        for (int i = 0; i < nx; ++i) (void)render_pixel(S, i, j, nx, ny, ns, 1.0f, S.background, S.gradient, 1984ull);
+    g_ray_out = nullptr; g_ray_stride = 0;
+    const int n = (int)(rays.size() / 8);
+    const int m = n < cap ? n : cap;
+    if (out) memcpy(out, rays.data(), (size_t)m * 8 * sizeof(float));
+    return m;
+}
+
 void orc_scene_census(int h, int* out) {
     const Scene& S = *g_scenes[h];
     for (int k = 0; k < 12; ++k) out[k] = 0;

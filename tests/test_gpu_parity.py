@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-4
-KERNELS = [0, 3, 4]   # pixel (the reference's loop nest, GPU-side cross-check), staged (the default), wavefront (experimental; spheres-only scenes)
+KERNELS = [0, 3]   # pixel (the reference's loop nest on the reference's full tree: GPU-side cross-check), staged + tier kernel (the default)
 
 
 def assert_frames_equal(got, ref, what=""):
@@ -34,8 +34,8 @@ def render(art, hs, kernel=DEFAULT_KERNEL, opts=None, **frame_kw):
     art.reset_options()
     art.set_option("kernel", kernel)
     opts = dict(opts or {})
-    if "tier0_auto" not in opts and any(k.startswith(("tier0_", "tier1_", "heavy_", "sparse_wg")) for k in opts):
-        opts["tier0_auto"] = 0          # hand-set tier sizes only apply with the automatic sizing off
+    if "tier_auto" not in opts and any(k.startswith(("tier1_", "heavy_", "sparse_wg")) for k in opts):
+        opts["tier_auto"] = 0          # hand-set tier sizes only apply with the automatic sizing off
     for k, v in opts.items():
         art.set_option(k, v)
     ds = art.DeviceScene(hs)
@@ -168,11 +168,11 @@ def test_row_partition_is_invisible(gpu, orc):
 
 def test_partitions_with_automatic_tier_sizing(gpu, orc):
     """What each rank of a 2-, 4- or 8-GPU run does: the cost-aware schedule sizes its tiers from the share of the frame
-    (tier 0 = a whole workgroup per pixel for small shares).  Still the whole frame's pixels, bit for bit."""
+    (the emptier the machine, the more pixels get a wave of the tier kernel).  Still the whole frame's pixels, bit for bit."""
     nx, ny, ns = 240, 192, 16
     hs = gpu.HostScene("bouncing", nx, ny)
     ref, cnt = orc.OracleScene("bouncing", nx, ny).render(ns)
-    opts = {"tier0_auto": 1, "split_samples": 4, "presplit_samples": 2}
+    opts = {"tier_auto": 1, "split_samples": 4, "presplit_samples": 2}
     for world in (1, 2, 4, 8):
         full = np.full((ny, nx, 3), np.nan, np.float32)
         rays = 0
@@ -199,15 +199,14 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
                 (3, {"sparse_stride": 2, "heavy_factor_x10": 12, "sparse_priority": 0, "sparse_eager": 1}), (3, {"tier1_pixels": 0, "sparse_stride": 16}),
                 (3, {"split_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096}), (3, {"split_samples": 3, "tier1_factor_x10": 15}),
                 (3, {"split_samples": 3, "presplit_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 12}), (3, {"split_samples": 2, "presplit_samples": 1, "tier1_pixels": 0}),
-                (3, {"split_samples": 3, "tier0_factor_x10": 10, "tier0_pixels": 32, "heavy_factor_x10": 10}), (3, {"split_samples": 2, "tier0_pixels": 0}),
+                # the tier kernel off (tier 1 empty), the cost prior off (an unranked first part), both
+                (3, {"split_samples": 3, "tier_kernel": 0, "heavy_factor_x10": 10}), (3, {"split_samples": 2, "prior": 0}), (3, {"split_samples": 2, "presplit_samples": 1, "prior": 0, "tier_kernel": 0, "heavy_factor_x10": 10}),
+                (3, {"split_samples": 3, "presplit_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 8192, "tier1_depth": 1}),
                 (3, {"lds_mode": 0}), (3, {"lds_mode": 3}), (3, {"lds_mode": 1}), (3, {"steps_per_trip": 1, "shade_threshold": 1, "diel_threshold": 1, "newpath_threshold": 1}),
                 (3, {"steps_per_trip": 11, "shade_threshold": 64, "diel_threshold": 64, "newpath_threshold": 64}), (3, {"threads": 256, "wg_per_cu": 3}),
                 (3, {"threads": 64, "wg_per_cu": 8, "shade_threshold": 40, "newpath_threshold": 3}),
-                (4, {}), (4, {"wf_threads": 1024, "lds_mode": 1}), (4, {"wf_threads": 256, "wf_slots": 384, "wf_wg_per_cu": 3, "lds_mode": 0, "wf_pause_lanes": 64}),
-                (4, {"wf_pause_lanes": 1, "steps_per_trip": 3}),
                 (0, {"lds_mode": 0}), (3, {"bvh_collapse": 0}), (3, {"bvh_collapse": 1}), (3, {"bvh_collapse": 1, "leaf_threshold": 1, "steps_per_trip": 3}),
                 (3, {"bvh_collapse": 0, "leaf_threshold": 64, "steps_per_trip": 20}), (3, {"leaf_threshold": 1}), (3, {"leaf_threshold": 33, "steps_per_trip": 2}),
-                (4, {"bvh_collapse": 0}), (4, {"bvh_collapse": 1}),
                 # tier 3 (listed pixels below the sparse threshold): on ordinary lanes, on semi workgroups, none; a second ranking
                 (3, {"split_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 30, "semi_stride": 0}), (3, {"split_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 30, "semi_stride": 2}),
                 (3, {"split_samples": 2, "presplit_samples": 1, "heavy_factor_x10": 12, "sparse_factor_x10": 20, "semi_stride": 4, "tier1_pixels": 0}),
@@ -220,7 +219,7 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
         assert np.array_equal(fb.view(np.uint32), base.view(np.uint32)), (kernel, opts)
     hs2 = gpu.HostScene("cornell_smoke", 48, 48)
     base2, _ = render(gpu, hs2, 0, ns=4)
-    for kernel, opts in [(3, {}), (3, {"lds_mode": 0, "diel_threshold": 1}), (3, {"lds_mode": 1, "box_threshold": 1, "medium_threshold": 1}), (3, {"steps_per_trip": 2, "shade_threshold": 60, "box_threshold": 64, "medium_threshold": 64}),
+    for kernel, opts in [(3, {}), (3, {"split_samples": 2, "presplit_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096}), (3, {"split_samples": 2, "tier_kernel": 0}), (3, {"lds_mode": 0, "diel_threshold": 1}), (3, {"lds_mode": 1, "box_threshold": 1, "medium_threshold": 1}), (3, {"steps_per_trip": 2, "shade_threshold": 60, "box_threshold": 64, "medium_threshold": 64}),
                          (3, {"bvh_collapse": 0}), (3, {"bvh_collapse": 1, "leaf_threshold": 1}), (3, {"bvh_collapse": 2, "leaf_threshold": 40, "steps_per_trip": 5})]:
         fb, _ = render(gpu, hs2, kernel, opts, ns=4)
         assert np.array_equal(fb.view(np.uint32), base2.view(np.uint32)), (kernel, opts)
@@ -331,9 +330,9 @@ def test_drop_in_executable_writes_the_reference_ppm(gpu, orc, tmp_path):
 
 @pytest.mark.parametrize("name,nx,ny,ns", [("bouncing", 160, 96, 16), ("cornell", 96, 96, 12), ("final", 80, 80, 8)])
 def test_split_frame_schedule_matches_oracle(gpu, orc, name, nx, ny, ns):
-    """The cost-aware schedule (frame split at a sample boundary, pixels parked and resumed, heavy pixels on sparse and
-    single-pixel wide-traversal waves) is scheduling only: with aggressive settings every kind of wave is exercised and
-    the frame must still equal the oracle bit for bit."""
+    """The cost-aware schedule (frame split at sample boundaries, pixels parked and resumed, heavy pixels on sparse waves
+    and on the tier kernel's one-pixel waves: trace_wave over spheres, quads, boxes, instances and media) is scheduling
+    only: with aggressive settings every kind of wave is exercised and the frame must still equal the oracle bit for bit."""
     img, iw, ih = gpu.default_texture(name)
     hs = gpu.HostScene(name, nx, ny, img, iw, ih)
     ref, cnt = orc.OracleScene(name, nx, ny, img, iw, ih).render(ns)
@@ -344,11 +343,12 @@ def test_split_frame_schedule_matches_oracle(gpu, orc, name, nx, ny, ns):
                  {"split_samples": 4, "presplit_samples": 2, "heavy_factor_x10": 12, "tier1_factor_x10": 20, "tier1_pixels": 64},
                  {"split_samples": 3, "presplit_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096, "sparse_wg_percent": 100},
                  {"split_samples": 4, "presplit_samples": 3, "heavy_factor_x10": 11, "tier1_pixels": 0, "sparse_stride": 16},
-                 # tier 0 (whole workgroup per pixel, spheres-only scenes; ignored elsewhere) with and without the other tiers
-                 {"split_samples": 4, "presplit_samples": 2, "heavy_factor_x10": 10, "tier0_factor_x10": 10, "tier0_pixels": 64, "tier1_factor_x10": 10},
-                 {"split_samples": 2, "heavy_factor_x10": 12, "tier0_factor_x10": 15, "tier0_pixels": 16, "tier1_pixels": 0, "sparse_stride": 4},
-                 {"split_samples": 3, "heavy_factor_x10": 10, "tier0_factor_x10": 10, "tier0_pixels": 4096, "sparse_wg_percent": 100, "threads": 256, "wg_per_cu": 3},
-                 {"split_samples": 4, "tier0_pixels": 0, "heavy_factor_x10": 12}):
+                 # every pixel on the tier kernel (list from 1.0 x the mean, no cap to speak of), one pixel per wave and several
+                 {"split_samples": 4, "presplit_samples": 2, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 65536, "tier1_depth": 1, "sparse_work_percent": 100},
+                 {"split_samples": 2, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 65536, "tier1_depth": 16, "sparse_work_percent": 100, "threads": 256, "wg_per_cu": 3},
+                 # without the cost prior (unranked first part), without the tier kernel
+                 {"split_samples": 4, "presplit_samples": 2, "prior": 0, "heavy_factor_x10": 12, "tier1_factor_x10": 15, "tier1_pixels": 4096},
+                 {"split_samples": 4, "tier_kernel": 0, "heavy_factor_x10": 12}):
         fb, st = render(gpu, hs, 3, opts, ns=ns)
         assert st.rays == cnt["rays"], (opts, st.rays, cnt["rays"])
         assert_frames_equal(fb, ref, f"{name} {opts}")

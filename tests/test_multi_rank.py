@@ -89,3 +89,14 @@ def test_c_abi_row_partition_round_trips():
                 assert art.row_owner(int(j), tile, world) == (r, k)
                 seen[j] += 1
         assert (seen == 1).all()
+
+
+def test_missing_rccl_library_is_an_error_status_not_a_crash():
+    """rt_multi_render loads RCCL with dlopen when a gather is needed; a box without the library must get RT_ERR_HIP and the
+    loader's message (the message was once built from a second, null dlerror()).  Host only, no device."""
+    import accelerated_ray_tracer_amd as art
+    L = art.rt_lib()
+    st = L.rt_multi_probe_rccl(b"librccl_this_name_does_not_exist.so.9")
+    assert st == 3, st                                                   # RT_ERR_HIP
+    detail = L.rt_last_error_detail().decode()
+    assert "cannot load librccl.so" in detail and "librccl_this_name_does_not_exist.so.9" in detail, detail

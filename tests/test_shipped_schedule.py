@@ -188,3 +188,56 @@ def test_raytracer_gpus_flag(gpu, tmp_path):
     too_many = torch.cuda.device_count() + 1
     bad = subprocess.run([exe, "--scene", "bouncing", "--nx", "64", "--ny", "40", "--ns", "4", "--gpus", str(too_many)], capture_output=True, timeout=120)
     assert bad.returncode == 99, bad.stderr.decode()
+
+
+@pytest.mark.parametrize("world,ny", [(3, 50), (8, 136), (8, 37)])
+def test_reassembly_for_worlds_a_one_gpu_box_cannot_run(gpu, world, ny):
+    """rt_multi_render's un-interleave step (rt_uninterleave_kernel: staging[rank][local_row] -> frame[global_row]) on a
+    synthetic `world`: the staging buffer is filled on this GPU with the rank-local renders of every rank, padded to the
+    common max_rows exactly as the gather would deliver them -- including ny that is no multiple of tile_rows * world --
+    and the reassembled frame must be the whole frame bit for bit."""
+    import torch
+    import ctypes as C
+    nx, ns, tile_rows = 96, 8, 4
+    hs = gpu.HostScene("random_scene", nx, ny)
+    ds = gpu.DeviceScene(hs)
+    try:
+        whole, _ = render_default(gpu, ds, hs, nx=nx, ny=ny, ns=ns)
+        parts, max_rows = [], 0
+        for r in range(world):
+            part, st = render_default(gpu, ds, hs, nx=nx, ny=ny, ns=ns, tile_rows=tile_rows, tile_first=r, tile_stride=world)
+            parts.append(part)
+            max_rows = max(max_rows, part.shape[0])
+        staging = torch.full((world, max_rows, nx, 3), float("nan"), dtype=torch.float32, device="cuda")
+        for r, part in enumerate(parts):
+            if part.shape[0]:
+                staging[r, : part.shape[0]] = torch.from_numpy(part).cuda()
+        frame = torch.zeros((ny, nx, 3), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        st = gpu.rt_lib().rt_multi_debug_uninterleave(C.c_void_p(staging.data_ptr()), C.c_void_p(frame.data_ptr()), nx, ny, tile_rows, world, max_rows)
+        assert st == 0, gpu.rt_lib().rt_last_error_detail()
+        assert bits_equal(frame.cpu().numpy(), whole)
+        for j in range(ny):   # ... and the host-side owner arithmetic names the same rows
+            d, l = gpu.row_owner(j, tile_rows, world)
+            assert bits_equal(parts[d][l], whole[j])
+    finally:
+        ds.close()
+
+
+def test_book1_full_size_default_schedule(gpu, orc):
+    """BASELINE configs[1] as the book defines it (`book1`: the book's material rules, static spheres, gradient sky) at its
+    full size, 1200x800 @ 100 spp, default options: 8-row bands and their ray counts against the oracle."""
+    nx, ny, ns = 1200, 800, 100
+    hs = gpu.HostScene("book1", nx, ny)
+    ds = gpu.DeviceScene(hs)
+    try:
+        fb, st = render_default(gpu, ds, hs, nx=nx, ny=ny, ns=ns)
+        assert st.samples == nx * ny * ns and st.kernel_variant // 1000 == 3
+        o = orc.OracleScene("book1", nx, ny)
+        for row0 in (0, 296, 408, 792):
+            ref, cnt = o.render(ns, row0=row0, row1=row0 + 8)
+            assert bits_equal(fb[row0:row0 + 8], ref[row0:row0 + 8]), row0
+            band, st_band = render_default(gpu, ds, hs, nx=nx, ny=ny, ns=ns, tile_rows=8, tile_first=row0 // 8, tile_stride=10 ** 6)
+            assert st_band.rays == cnt["rays"] and bits_equal(band, ref[row0:row0 + 8]), row0
+    finally:
+        ds.close()

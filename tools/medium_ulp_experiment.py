@@ -32,6 +32,9 @@ def stats(a, b):
 
 if sys.argv[1] == "render":
     import oracle, accelerated_ray_tracer_amd as art
+    # the perturbable logf only exists in the diagnostic twin of the oracle (-DORC_DIAG); load that one, explicitly
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "librt_oracle_diag.so"], check=True, capture_output=True)
+    oracle.LIB_PATH = os.path.join(ROOT, "oracle", "librt_oracle_diag.so")
     meta = json.load(open(os.path.join(ROOT, "tests/golden/reference_image_pins.json")))
     tr, tf, ts = meta["tile_rows"], meta["tile_first"], meta["tile_stride"]
     row0 = (tf + TILE * ts) * tr
