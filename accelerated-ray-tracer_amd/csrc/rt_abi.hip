@@ -62,8 +62,15 @@ struct rt_options {
     int heavy_factor_x10 = 20;   // a pixel is listed ("heavy") when its cost so far is >= this/10 x the mean ...
     int sparse_factor_x10 = 40;  // ... and goes to a sparse wave (tier 2) from this/10 x the mean; below, ordinary lanes take it first (tier 3)
     int heavy_max_tiles = 0;     // 0 = as many as the sparse workgroups hold at once
-    int semi_stride = 0;         // lanes per pixel in the workgroups serving tier 3 (0 = ordinary lanes take tier 3 first)
+    int semi_stride = 1;         // lanes per pixel in the workgroups serving tier 3 (0 = ordinary lanes take tier 3 first); 1 = whole waves of
+                                 // tier-3 pixels, which with semi_priority 1 measured 100.2 -> 94.3 ms on the headline (profiles/r03_batch6)
     int sparse_priority = 3;
+    int group_kernel = 0;        // (experiment, off: measured slower than sparse waves, profiles/r03_group_kernel_experiment_*.log) tier 2 of the list goes to the group kernel (rt_kernel_group.h: several pixels per wave in lockstep)
+                                 // where the scene has a group tree; 0 = sparse waves of the main kernel
+    int group_lanes = 8;         // lanes per pixel in the group kernel: 8 or 16 (read by rt_scene_create: it builds the G-ary tree)
+    int group_depth = 2;         // pixels a group is meant to take, one after the other
+    int tier_priority = 3;       // s_setprio level of the tier kernel's waves
+    int semi_priority = 1;       // s_setprio level of the semi workgroups' waves (tier 3 on workgroups of its own)
     int sparse_eager = 0;
     int sparse_work_percent = 5;  // tiers 0-2 hold at most this share of the frame's work (rays so far); dearer-than-average pixels beyond it go to tier 3
     int sparse_wg_percent = 35;   // at most this share of the workgroups starts in sparse mode
@@ -134,6 +141,8 @@ struct rt_scene {
     unsigned int* d_cal_cost = nullptr;           // cost prior: rays per pixel of the calibration frame (cal_nx x cal_ny at 4 spp)
     int cal_nx = 0, cal_ny = 0;
     hipStream_t tier_stream = nullptr;            // the tier kernel's stream (forked from / joined to the caller's stream by events)
+    hipStream_t group_stream = nullptr;           // the group kernel's
+    hipEvent_t ev_gjoin[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ranked_frame = false;                    // the pending frame used the cost-aware schedule
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -604,6 +613,11 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "tier1_pixels") { if (value < 0 || value > 65536) return invalid("tier1_pixels: 0..65536"); g_opt.tier1_pixels = value; }
     else if (k == "semi_stride") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return invalid("semi_stride: 0, 1, 2, 4 or 8"); g_opt.semi_stride = value; }
     else if (k == "sparse_eager") { if (value < 0 || value > 1) return invalid("sparse_eager: 0 or 1"); g_opt.sparse_eager = value; }
+    else if (k == "group_kernel") { if (value < 0 || value > 1) return invalid("group_kernel: 0 or 1"); g_opt.group_kernel = value; }
+    else if (k == "group_lanes") { if (value != 8 && value != 16) return invalid("group_lanes: 8 or 16 (read by rt_scene_create)"); g_opt.group_lanes = value; }
+    else if (k == "group_depth") { if (value < 1 || value > 64) return invalid("group_depth: 1..64"); g_opt.group_depth = value; }
+    else if (k == "tier_priority") { if (value < 0 || value > 3) return invalid("tier_priority: 0..3"); g_opt.tier_priority = value; }
+    else if (k == "semi_priority") { if (value < 0 || value > 3) return invalid("semi_priority: 0..3"); g_opt.semi_priority = value; }
     else if (k == "sparse_priority") { if (value < 0 || value > 3) return invalid("sparse_priority: 0..3"); g_opt.sparse_priority = value; }
     else if (k == "sparse_work_percent") { if (value < 0 || value > 100) return invalid("sparse_work_percent: 0..100"); g_opt.sparse_work_percent = value; }
     else if (k == "sparse_wg_percent") { if (value < 1 || value > 100) return invalid("sparse_wg_percent: 1..100"); g_opt.sparse_wg_percent = value; }
@@ -636,6 +650,8 @@ rt_status rt_scene_destroy(rt_scene* s) {
     if (s->d_rank) (void)hipFree(s->d_rank);
     if (s->d_cal_cost) (void)hipFree(s->d_cal_cost);
     if (s->tier_stream) (void)hipStreamDestroy(s->tier_stream);
+    if (s->group_stream) (void)hipStreamDestroy(s->group_stream);
+    for (int k = 0; k < 4; ++k) if (s->ev_gjoin[k]) (void)hipEventDestroy(s->ev_gjoin[k]);
     for (int k = 0; k < 4; ++k) { if (s->ev_fork[k]) (void)hipEventDestroy(s->ev_fork[k]); if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]); }
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
@@ -772,6 +788,67 @@ rt_status build_tier_data(rt_scene* s, const rt_scene_desc* d) {
     s->dev.leaf_lo = reinterpret_cast<const float4*>(d_lo); s->dev.leaf_hi = reinterpret_cast<const float4*>(d_hi); s->dev.slot_ranges = d_ranges;
     s->dev.n_leaves = m; s->dev.n_slots = slots; s->dev.n_media_leaves = media;
     s->dev.media_ord[0] = media_ord[0]; s->dev.media_ord[1] = media_ord[1];
+    return RT_OK;
+}
+
+// Group tree (rt_kernel_group.h): a G-ary hierarchy of union boxes over the same leaf sequence (G = option group_lanes).
+// Level 0 = the leaves; level k + 1 = the exact unions (float min / max) of G consecutive level-k boxes; every level padded
+// to a multiple of G (padding entries carry hi.w = 0).  Spheres-only scenes of up to G^4 leaves.
+rt_status build_group_tree(rt_scene* s, const rt_scene_desc* d) {
+    s->dev.grp_lo = s->dev.grp_hi = nullptr; s->dev.grp_lanes = 0; s->dev.grp_top = 0; s->dev.grp_total = 0;
+    for (int k = 0; k < 4; ++k) s->dev.grp_off[k] = 0;
+    if (!s->spheres_only) return RT_OK;
+    const int G = g_opt.group_lanes;
+    struct entry { float lo[4], hi[4]; };
+    std::vector<std::vector<entry>> levels;
+    {
+        std::vector<entry> l0;
+        for (int i = 0; i < d->n_nodes; ++i) {
+            if (d->nodes[i].prim < 0) continue;
+            entry e;
+            for (int c = 0; c < 3; ++c) { e.lo[c] = d->nodes[i].bmin[c]; e.hi[c] = d->nodes[i].bmax[c]; }
+            memcpy(&e.lo[3], &d->nodes[i].prim, 4); e.hi[3] = 1.0f;
+            l0.push_back(e);
+        }
+        if (l0.empty()) return RT_OK;
+        levels.push_back(l0);
+    }
+    while ((int)levels.back().size() > G) {
+        if (levels.size() >= 4) return RT_OK;                       // more than G^4 leaves: no group kernel for this scene
+        const std::vector<entry>& below = levels.back();
+        std::vector<entry> up;
+        for (size_t j = 0; j < below.size(); j += (size_t)G) {
+            entry e;
+            for (int c = 0; c < 3; ++c) { e.lo[c] = FLT_MAX; e.hi[c] = -FLT_MAX; }
+            for (size_t k = j; k < j + (size_t)G && k < below.size(); ++k)
+                for (int c = 0; c < 3; ++c) { e.lo[c] = fminf(e.lo[c], below[k].lo[c]); e.hi[c] = fmaxf(e.hi[c], below[k].hi[c]); }
+            e.lo[3] = 0.0f; e.hi[3] = 1.0f;
+            up.push_back(e);
+        }
+        levels.push_back(up);
+    }
+    std::vector<float> lo, hi;
+    int off = 0;
+    for (size_t k = 0; k < levels.size(); ++k) {
+        s->dev.grp_off[k] = off;
+        const size_t padded = (levels[k].size() + (size_t)G - 1) / (size_t)G * (size_t)G;
+        for (size_t j = 0; j < padded; ++j) {
+            entry e;
+            if (j < levels[k].size()) e = levels[k][j];
+            else { for (int c = 0; c < 4; ++c) { e.lo[c] = 0.0f; e.hi[c] = 0.0f; } const int32_t none = -1; memcpy(&e.lo[3], &none, 4); }
+            lo.insert(lo.end(), e.lo, e.lo + 4); hi.insert(hi.end(), e.hi, e.hi + 4);
+        }
+        off += (int)padded;
+    }
+    const float* d_lo = nullptr; const float* d_hi = nullptr;
+    rt_status st = upload(lo.data(), lo.size(), &d_lo);
+    if (st != RT_OK) return st;
+    s->allocs.push_back(const_cast<float*>(d_lo));
+    st = upload(hi.data(), hi.size(), &d_hi);
+    if (st != RT_OK) return st;
+    s->allocs.push_back(const_cast<float*>(d_hi));
+    s->dev.grp_lo = reinterpret_cast<const float4*>(d_lo); s->dev.grp_hi = reinterpret_cast<const float4*>(d_hi);
+    s->dev.grp_lanes = G; s->dev.grp_top = (int32_t)levels.size() - 1; s->dev.grp_total = off;
     return RT_OK;
 }
 
@@ -973,13 +1050,17 @@ rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_sce
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         e = hipStreamCreateWithPriority(&s->tier_stream, hipStreamNonBlocking, prio_hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s->group_stream, hipStreamNonBlocking, prio_hi);
         for (int k = 0; k < 4 && e == hipSuccess; ++k) {
             e = hipEventCreateWithFlags(&s->ev_fork[k], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_gjoin[k], hipEventDisableTiming);
         }
         if (e != hipSuccess) { g_last_hip_error = (int)e; g_detail = "creating the tier stream failed"; rt_scene_destroy(s); return RT_ERR_HIP; }
     }
     st = build_tier_data(s, d);
+    if (st != RT_OK) { rt_scene_destroy(s); return st; }
+    st = build_group_tree(s, d);
     if (st != RT_OK) { rt_scene_destroy(s); return st; }
     st = build_walk(s, d);
     if (st != RT_OK) { rt_scene_destroy(s); return st; }
@@ -1149,7 +1230,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     const int tiles_y = (local_rows + 7) / 8;
     if ((long long)fp.tiles_x * tiles_y * 64 >= (1ll << 31)) return invalid("frame too large");
     fp.work_items = (uint32_t)fp.tiles_x * (uint32_t)tiles_y * 64u;
-    fp.sparse_priority = g_opt.sparse_priority; fp.sparse_eager = g_opt.sparse_eager;
+    fp.sparse_priority = g_opt.sparse_priority; fp.sparse_eager = g_opt.sparse_eager; fp.semi_priority = g_opt.semi_priority; fp.tier_priority = g_opt.tier_priority;
     fp.steps_per_trip = g_opt.steps_per_trip;
     fp.shade_threshold = g_opt.shade_threshold;
     fp.leaf_threshold = g_opt.leaf_threshold;
@@ -1211,12 +1292,12 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     // Lean family: the main kernel's 4 x 96 registers per SIMD leave 128 free, so ONE tier workgroup (four waves, one per
     // SIMD, <= 128 VGPRs) is resident on a CU beside a full main grid if the LDS left over holds its image.  Other families:
     // no register room beside a full main grid; the ranking makes main workgroups leave (main_skip_wgs) and a tier workgroup
-    // has what one of them had.  The image always holds the leaf arrays; spheres, then materials + textures, where they fit.
+    // has what one of them had.  The image always holds the leaf arrays; spheres, materials and textures too where all of them fit.
     bool tier_possible = false;
     size_t tier_lds = 0;
     unsigned tier_grid = 0;
     int tier_waves_per_main_wg = 0;
-    fp.tier_lds_spheres = fp.tier_lds_materials = 0;
+    fp.tier_lds_scene = 0;
     if (kernel == RT_KERNEL_STAGED && g_opt.tier_kernel && s->dev.leaf_lo != nullptr && g_opt.tier1_pixels > 0) {
         size_t budget;
         if (lean_family) {
@@ -1229,15 +1310,33 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             tier_waves_per_main_wg = (int)(block.x / 64u);
         }
         const int ns_ = s->dev.n_slots, nsph = s->dev.n_spheres, nm = s->dev.n_materials, nt = s->dev.n_textures;
-        if (rt_tier_lds_bytes(ns_, nsph, false, nm, nt, false) <= budget) {
+        if (rt_tier_lds_bytes(ns_, nsph, nm, nt, false) <= budget) {
             tier_possible = true;
-            if (rt_tier_lds_bytes(ns_, nsph, true, nm, nt, false) <= budget) fp.tier_lds_spheres = 1;
-            if (rt_tier_lds_bytes(ns_, nsph, fp.tier_lds_spheres != 0, nm, nt, true) <= budget) fp.tier_lds_materials = 1;
-            tier_lds = rt_tier_lds_bytes(ns_, nsph, fp.tier_lds_spheres != 0, nm, nt, fp.tier_lds_materials != 0);
+            if (rt_tier_lds_bytes(ns_, nsph, nm, nt, true) <= budget) fp.tier_lds_scene = 1;
+            tier_lds = rt_tier_lds_bytes(ns_, nsph, nm, nt, fp.tier_lds_scene != 0);
             // the tier kernel's grid is fixed before the ranking has sized the tier: what can be resident beside the main
             // grid (one workgroup per CU) and as much again queued behind it; workgroups beyond the tier's size leave at once
             tier_grid = lean_family ? (unsigned)(2 * g_num_cu) : (unsigned)(g_num_cu * per_cu_resident) * (block.x / RT_TIER_THREADS > 0 ? block.x / RT_TIER_THREADS : 1u) / 2u;
             if (tier_grid < 1u) tier_grid = 1u;
+        }
+    }
+    // ---- the group kernel of ranked launches (rt_kernel_group.h): tier 2, 64 / G pixels per wave.  Lean family only: like a
+    // tier workgroup a group workgroup (four waves, <= 128 VGPRs) is resident beside a full main grid; a CU's spare registers
+    // hold one such wave per SIMD, so a CU hosts a tier workgroup OR a group workgroup next to its two main workgroups.
+    bool group_possible = false;
+    size_t group_lds = 0;
+    unsigned group_grid = 0;
+    fp.group_lds_scene = 0;
+    if (kernel == RT_KERNEL_STAGED && g_opt.group_kernel && lean_family && s->dev.grp_lo != nullptr && g_opt.sparse_stride > 0) {
+        const size_t used = (size_t)per_cu_resident * (lds_bytes + 512);
+        const size_t budget = g_lds_per_cu > used + 1024 ? g_lds_per_cu - used - 1024 : 0;
+        const size_t tree = (size_t)s->dev.grp_total * 32;
+        const size_t scene = s->sphere_bytes + s->shade_bytes;
+        if (tree <= budget) {
+            group_possible = true;
+            if (tree + scene <= budget) fp.group_lds_scene = 1;
+            group_lds = tree + (fp.group_lds_scene ? scene : 0);
+            group_grid = (unsigned)(2 * g_num_cu);
         }
     }
     out.kernel_variant = kernel * 1000 + lds_mode * 100 + s->tex_level * 10 + (s->spheres_only ? 1 : 0);
@@ -1280,8 +1379,16 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
                                    : rt_launch_tier_general(s->tex_level, s->need_uv, s->dev, q, dim3(tier_grid), tier_lds, s->tier_stream));
             HIPCHK(hipEventRecord(s->ev_join[pi], s->tier_stream));
         }
+        const bool groups = ranked && group_possible;
+        if (groups) {
+            if (!tiers) HIPCHK(hipEventRecord(s->ev_fork[pi], stream));
+            HIPCHK(hipStreamWaitEvent(s->group_stream, s->ev_fork[pi], 0));
+            HIPCHK(rt_launch_group_spheres(s->tex_level, s->dev.grp_lanes, s->dev, q, dim3(group_grid), group_lds, s->group_stream));
+            HIPCHK(hipEventRecord(s->ev_gjoin[pi], s->group_stream));
+        }
         HIPCHK(launch_render(kernel, lds_mode, s, q, grid_q, block, lds_bytes, stream));
         if (tiers) HIPCHK(hipStreamWaitEvent(stream, s->ev_join[pi], 0));
+        if (groups) HIPCHK(hipStreamWaitEvent(stream, s->ev_gjoin[pi], 0));
         return RT_OK;
     };
     if (g_opt.lpt && kernel == RT_KERNEL_STAGED && f->ns >= 2 * g_opt.split_samples && n_tiles >= 64 && n_pixels < (1ull << 31)) {
@@ -1333,6 +1440,9 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             rp.tier_possible = tier_possible ? 1 : 0;
             rp.tier1_pixels = e_tier1_pixels; rp.tier1_depth = e_tier1_depth;
             rp.tier_wgs_cap = (int32_t)tier_grid; rp.tier_waves_per_main_wg = tier_waves_per_main_wg;
+            rp.group_wgs_cap = group_possible ? (int32_t)group_grid : 0;
+            rp.group_pixels_per_wg = (RT_TIER_THREADS / 64) * (64 / (s->dev.grp_lanes > 0 ? s->dev.grp_lanes : 8));
+            rp.group_depth = g_opt.group_depth;
             rp.nx = f->nx; rp.smooth_percent = g_opt.cost_smooth_percent;
             if (e_sparse_factor < e_heavy_factor) e_sparse_factor = e_heavy_factor;
             rp.heavy_factor = (float)e_heavy_factor / 10.0f; rp.sparse_factor = (float)e_sparse_factor / 10.0f; rp.tier1_factor = (float)e_tier1_factor / 10.0f;

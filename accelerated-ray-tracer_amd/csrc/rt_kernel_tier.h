@@ -166,16 +166,21 @@ DEV bool trace_wave(const TierView& tv, const SceneView& sc, const Ray& r, HitIn
     return true;
 }
 
-template <bool SPHERES_ONLY, int TEX, bool NEED_UV>
+// LDS_SCENE: the workgroup's LDS image also holds the spheres, materials and textures (a template parameter, not a run-time
+// flag, so that those reads are LDS instructions and not flat loads through a pointer of unknown address space)
+template <bool SPHERES_ONLY, int TEX, bool NEED_UV, bool LDS_SCENE>
 __global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4 : 3) rt_tier_kernel(rt_scene_dev sd, rt_frame_params fp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const rt_rank_info* q = fp.rank;
     const int my_wgs = q->tier1_wgs;
     const uint32_t n_items = q->tier1_items;
     if ((int)blockIdx.x >= my_wgs) return;        // the grid is fixed before the ranking has sized the tier
-    __builtin_amdgcn_s_setprio(3);                 // these waves are the frame's critical path
+    // these waves are the frame's critical path: they win instruction-issue arbitration on their SIMD (option tier_priority)
+    if (fp.tier_priority >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (fp.tier_priority == 2) __builtin_amdgcn_s_setprio(2);
+    else if (fp.tier_priority == 1) __builtin_amdgcn_s_setprio(1);
 
-    // ---- the workgroup's LDS image: leaf arrays, slot unions, then (where they fit: host's plan) spheres, materials, textures
+    // ---- the workgroup's LDS image: leaf arrays, slot unions, then (LDS_SCENE: the host's plan) spheres, materials, textures
     SceneView sc;
     sc.nodes = sd.nodes; sc.spheres = sd.spheres; sc.quads = sd.quads; sc.boxes = sd.boxes; sc.instances = sd.instances;
     sc.media = sd.media; sc.materials = sd.materials; sc.textures = sd.textures; sc.images = sd.images; sc.n_nodes = sd.n_nodes;
@@ -188,21 +193,19 @@ __global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4
         for (int k = (int)threadIdx.x; k < n_pad; k += (int)blockDim.x) { dlo[k] = sd.leaf_lo[k]; dhi[k] = sd.leaf_hi[k]; }
         const float4* sr = reinterpret_cast<const float4*>(sd.slot_ranges);
         for (int k = (int)threadIdx.x; k < sd.n_slots * 2; k += (int)blockDim.x) dr[k] = sr[k];
-        float4* next = dr + sd.n_slots * 2;
-        if (fp.tier_lds_spheres) {
+        if (LDS_SCENE) {
+            float4* dsph = dr + sd.n_slots * 2;
             const float4* s4 = reinterpret_cast<const float4*>(sd.spheres);
-            for (int k = (int)threadIdx.x; k < sd.n_spheres * 2; k += (int)blockDim.x) next[k] = s4[k];
-            sc.spheres = reinterpret_cast<const rt_sphere*>(next);
-            next += sd.n_spheres * 2;
-        }
-        if (fp.tier_lds_materials) {
+            for (int k = (int)threadIdx.x; k < sd.n_spheres * 2; k += (int)blockDim.x) dsph[k] = s4[k];
+            sc.spheres = reinterpret_cast<const rt_sphere*>(dsph);
+            float4* dmat = dsph + sd.n_spheres * 2;
             const float4* m4 = reinterpret_cast<const float4*>(sd.materials);
-            for (int k = (int)threadIdx.x; k < sd.n_materials * 2; k += (int)blockDim.x) next[k] = m4[k];
-            sc.materials = reinterpret_cast<const rt_material*>(next);
-            next += sd.n_materials * 2;
+            for (int k = (int)threadIdx.x; k < sd.n_materials * 2; k += (int)blockDim.x) dmat[k] = m4[k];
+            sc.materials = reinterpret_cast<const rt_material*>(dmat);
+            float4* dtex = dmat + sd.n_materials * 2;
             const float4* t4 = reinterpret_cast<const float4*>(sd.textures);
-            for (int k = (int)threadIdx.x; k < sd.n_textures * 4; k += (int)blockDim.x) next[k] = t4[k];
-            sc.textures = reinterpret_cast<const rt_texture*>(next);
+            for (int k = (int)threadIdx.x; k < sd.n_textures * 4; k += (int)blockDim.x) dtex[k] = t4[k];
+            sc.textures = reinterpret_cast<const rt_texture*>(dtex);
         }
         __syncthreads();
         tv.lo = dlo; tv.hi = dhi; tv.ranges = reinterpret_cast<const float*>(dr); tv.n_slots = sd.n_slots;
@@ -294,12 +297,16 @@ __global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4
 #endif
 }
 
-template <bool SO, int TX, bool UV>
-static hipError_t rt_launch_tier_one(const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st) {
+template <bool SO, int TX, bool UV, bool LS>
+static hipError_t rt_launch_tier_variant(const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st) {
     if (lds > 65536) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_tier_kernel<SO, TX, UV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_tier_kernel<SO, TX, UV, LS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((rt_tier_kernel<SO, TX, UV>), grid, dim3(RT_TIER_THREADS), lds, st, sd, fp);
+    hipLaunchKernelGGL((rt_tier_kernel<SO, TX, UV, LS>), grid, dim3(RT_TIER_THREADS), lds, st, sd, fp);
     return hipGetLastError();
+}
+template <bool SO, int TX, bool UV>
+static hipError_t rt_launch_tier_one(const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st) {
+    return fp.tier_lds_scene ? rt_launch_tier_variant<SO, TX, UV, true>(sd, fp, grid, lds, st) : rt_launch_tier_variant<SO, TX, UV, false>(sd, fp, grid, lds, st);
 }

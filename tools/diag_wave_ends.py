@@ -41,7 +41,23 @@ for k in range(n_waves):
     if a0 == 0: continue
     rows.append((a0 >> 32, a0 & 0xFFFFFFFF, a1 >> 60, (a1 >> 59) & 1, a1 & 0xFFFFFFF, k))
 rows.sort(reverse=True)
-import oracle
-print("last 24 waves: done_ms  last pixel fetched at ms  (duration)  queue  started-sparse  pixel(i,row)")
-for d_us, f_us, src, sp, pix, k in rows[:24]:
-    print(f"  wave {k:5d}  done {d_us/1000:7.2f}  fetched {f_us/1000:7.2f}  ({(d_us-f_us)/1000:6.2f} ms)  queue {src}  sparse {sp}  pixel ({pix % nx}, {pix // nx})")
+import oracle   # (experiment tooling: what the pixels that end the launch cost in all)
+orc = oracle.OracleScene("bouncing" if scene == "random_scene" else scene, nx, ny, img, iw, ih)
+Lo = oracle.lib()
+Lo.orc_row_pixel_rays.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_ulonglong, C.c_int, C.c_void_p]
+rows_global = art.local_rows_to_global(hs.frame(**fkw))
+bg = np.ascontiguousarray(orc.background, np.float32)
+row_cache = {}
+def pixel_rays(i, lrow):
+    j = int(rows_global[lrow])
+    if j not in row_cache:
+        out = np.zeros(nx, np.uint64)
+        Lo.orc_row_pixel_rays(orc.h, nx, ny, ns, bg.ctypes.data, orc.gradient, 1984, j, out.ctypes.data)
+        row_cache[j] = out
+    return int(row_cache[j][i]), j
+mean = st.rays / (len(rows_global) * nx)
+print(f"mean rays per pixel of this share: {mean:.0f}")
+print("last 16 waves: done_ms  last pixel fetched at ms  (duration)  queue  started-sparse  pixel(i,global row)  rays of that pixel (x mean)  us per ray")
+for d_us, f_us, src, sp, pix, k in rows[:16]:
+    r, j = pixel_rays(pix % nx, pix // nx)
+    print(f"  wave {k:5d}  done {d_us/1000:7.2f}  fetched {f_us/1000:7.2f}  ({(d_us-f_us)/1000:6.2f} ms)  queue {src}  sparse {sp}  pixel ({pix % nx}, {j})  {r} rays ({r / mean:.2f} x)  {(d_us - f_us) / max(r * (ns - 32) / ns, 1):.1f} us/ray")
