@@ -62,13 +62,10 @@ struct rt_options {
     int heavy_factor_x10 = 20;   // a pixel is listed ("heavy") when its cost so far is >= this/10 x the mean ...
     int sparse_factor_x10 = 40;  // ... and goes to a sparse wave (tier 2) from this/10 x the mean; below, ordinary lanes take it first (tier 3)
     int heavy_max_tiles = 0;     // 0 = as many as the sparse workgroups hold at once
-    int semi_stride = 1;         // lanes per pixel in the workgroups serving tier 3 (0 = ordinary lanes take tier 3 first); 1 = whole waves of
-                                 // tier-3 pixels, which with semi_priority 1 measured 100.2 -> 94.3 ms on the headline (profiles/r03_batch6)
+    int semi_stride = -1;        // lanes per pixel in the workgroups serving tier 3 (0 = ordinary lanes take tier 3 first); -1 = by kernel family:
+                                 // lean 1 -- whole waves of tier-3 pixels, which with semi_priority 1 measured 100.2 -> 94.3 ms on the headline
+                                 // (profiles/r03_priorities_whole.log) --, the others 0 (Book-2 final 352 -> 388 ms with 1, profiles/r03_general_defaults.log)
     int sparse_priority = 3;
-    int group_kernel = 0;        // (experiment, off: measured slower than sparse waves, profiles/r03_group_kernel_experiment_*.log) tier 2 of the list goes to the group kernel (rt_kernel_group.h: several pixels per wave in lockstep)
-                                 // where the scene has a group tree; 0 = sparse waves of the main kernel
-    int group_lanes = 8;         // lanes per pixel in the group kernel: 8 or 16 (read by rt_scene_create: it builds the G-ary tree)
-    int group_depth = 2;         // pixels a group is meant to take, one after the other
     int tier_priority = 3;       // s_setprio level of the tier kernel's waves
     int semi_priority = 1;       // s_setprio level of the semi workgroups' waves (tier 3 on workgroups of its own)
     int sparse_eager = 0;
@@ -141,8 +138,6 @@ struct rt_scene {
     unsigned int* d_cal_cost = nullptr;           // cost prior: rays per pixel of the calibration frame (cal_nx x cal_ny at 4 spp)
     int cal_nx = 0, cal_ny = 0;
     hipStream_t tier_stream = nullptr;            // the tier kernel's stream (forked from / joined to the caller's stream by events)
-    hipStream_t group_stream = nullptr;           // the group kernel's
-    hipEvent_t ev_gjoin[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ranked_frame = false;                    // the pending frame used the cost-aware schedule
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -611,11 +606,8 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "cost_smooth_percent") { if (value < 0 || value > 100) return invalid("cost_smooth_percent: 0..100"); g_opt.cost_smooth_percent = value; }
     else if (k == "tier1_depth") { if (value < 1 || value > 64) return invalid("tier1_depth: 1..64"); g_opt.tier1_depth = value; }
     else if (k == "tier1_pixels") { if (value < 0 || value > 65536) return invalid("tier1_pixels: 0..65536"); g_opt.tier1_pixels = value; }
-    else if (k == "semi_stride") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return invalid("semi_stride: 0, 1, 2, 4 or 8"); g_opt.semi_stride = value; }
+    else if (k == "semi_stride") { if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return invalid("semi_stride: -1 (by kernel family), 0, 1, 2, 4 or 8"); g_opt.semi_stride = value; }
     else if (k == "sparse_eager") { if (value < 0 || value > 1) return invalid("sparse_eager: 0 or 1"); g_opt.sparse_eager = value; }
-    else if (k == "group_kernel") { if (value < 0 || value > 1) return invalid("group_kernel: 0 or 1"); g_opt.group_kernel = value; }
-    else if (k == "group_lanes") { if (value != 8 && value != 16) return invalid("group_lanes: 8 or 16 (read by rt_scene_create)"); g_opt.group_lanes = value; }
-    else if (k == "group_depth") { if (value < 1 || value > 64) return invalid("group_depth: 1..64"); g_opt.group_depth = value; }
     else if (k == "tier_priority") { if (value < 0 || value > 3) return invalid("tier_priority: 0..3"); g_opt.tier_priority = value; }
     else if (k == "semi_priority") { if (value < 0 || value > 3) return invalid("semi_priority: 0..3"); g_opt.semi_priority = value; }
     else if (k == "sparse_priority") { if (value < 0 || value > 3) return invalid("sparse_priority: 0..3"); g_opt.sparse_priority = value; }
@@ -650,8 +642,6 @@ rt_status rt_scene_destroy(rt_scene* s) {
     if (s->d_rank) (void)hipFree(s->d_rank);
     if (s->d_cal_cost) (void)hipFree(s->d_cal_cost);
     if (s->tier_stream) (void)hipStreamDestroy(s->tier_stream);
-    if (s->group_stream) (void)hipStreamDestroy(s->group_stream);
-    for (int k = 0; k < 4; ++k) if (s->ev_gjoin[k]) (void)hipEventDestroy(s->ev_gjoin[k]);
     for (int k = 0; k < 4; ++k) { if (s->ev_fork[k]) (void)hipEventDestroy(s->ev_fork[k]); if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]); }
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
@@ -788,67 +778,6 @@ rt_status build_tier_data(rt_scene* s, const rt_scene_desc* d) {
     s->dev.leaf_lo = reinterpret_cast<const float4*>(d_lo); s->dev.leaf_hi = reinterpret_cast<const float4*>(d_hi); s->dev.slot_ranges = d_ranges;
     s->dev.n_leaves = m; s->dev.n_slots = slots; s->dev.n_media_leaves = media;
     s->dev.media_ord[0] = media_ord[0]; s->dev.media_ord[1] = media_ord[1];
-    return RT_OK;
-}
-
-// Group tree (rt_kernel_group.h): a G-ary hierarchy of union boxes over the same leaf sequence (G = option group_lanes).
-// Level 0 = the leaves; level k + 1 = the exact unions (float min / max) of G consecutive level-k boxes; every level padded
-// to a multiple of G (padding entries carry hi.w = 0).  Spheres-only scenes of up to G^4 leaves.
-rt_status build_group_tree(rt_scene* s, const rt_scene_desc* d) {
-    s->dev.grp_lo = s->dev.grp_hi = nullptr; s->dev.grp_lanes = 0; s->dev.grp_top = 0; s->dev.grp_total = 0;
-    for (int k = 0; k < 4; ++k) s->dev.grp_off[k] = 0;
-    if (!s->spheres_only) return RT_OK;
-    const int G = g_opt.group_lanes;
-    struct entry { float lo[4], hi[4]; };
-    std::vector<std::vector<entry>> levels;
-    {
-        std::vector<entry> l0;
-        for (int i = 0; i < d->n_nodes; ++i) {
-            if (d->nodes[i].prim < 0) continue;
-            entry e;
-            for (int c = 0; c < 3; ++c) { e.lo[c] = d->nodes[i].bmin[c]; e.hi[c] = d->nodes[i].bmax[c]; }
-            memcpy(&e.lo[3], &d->nodes[i].prim, 4); e.hi[3] = 1.0f;
-            l0.push_back(e);
-        }
-        if (l0.empty()) return RT_OK;
-        levels.push_back(l0);
-    }
-    while ((int)levels.back().size() > G) {
-        if (levels.size() >= 4) return RT_OK;                       // more than G^4 leaves: no group kernel for this scene
-        const std::vector<entry>& below = levels.back();
-        std::vector<entry> up;
-        for (size_t j = 0; j < below.size(); j += (size_t)G) {
-            entry e;
-            for (int c = 0; c < 3; ++c) { e.lo[c] = FLT_MAX; e.hi[c] = -FLT_MAX; }
-            for (size_t k = j; k < j + (size_t)G && k < below.size(); ++k)
-                for (int c = 0; c < 3; ++c) { e.lo[c] = fminf(e.lo[c], below[k].lo[c]); e.hi[c] = fmaxf(e.hi[c], below[k].hi[c]); }
-            e.lo[3] = 0.0f; e.hi[3] = 1.0f;
-            up.push_back(e);
-        }
-        levels.push_back(up);
-    }
-    std::vector<float> lo, hi;
-    int off = 0;
-    for (size_t k = 0; k < levels.size(); ++k) {
-        s->dev.grp_off[k] = off;
-        const size_t padded = (levels[k].size() + (size_t)G - 1) / (size_t)G * (size_t)G;
-        for (size_t j = 0; j < padded; ++j) {
-            entry e;
-            if (j < levels[k].size()) e = levels[k][j];
-            else { for (int c = 0; c < 4; ++c) { e.lo[c] = 0.0f; e.hi[c] = 0.0f; } const int32_t none = -1; memcpy(&e.lo[3], &none, 4); }
-            lo.insert(lo.end(), e.lo, e.lo + 4); hi.insert(hi.end(), e.hi, e.hi + 4);
-        }
-        off += (int)padded;
-    }
-    const float* d_lo = nullptr; const float* d_hi = nullptr;
-    rt_status st = upload(lo.data(), lo.size(), &d_lo);
-    if (st != RT_OK) return st;
-    s->allocs.push_back(const_cast<float*>(d_lo));
-    st = upload(hi.data(), hi.size(), &d_hi);
-    if (st != RT_OK) return st;
-    s->allocs.push_back(const_cast<float*>(d_hi));
-    s->dev.grp_lo = reinterpret_cast<const float4*>(d_lo); s->dev.grp_hi = reinterpret_cast<const float4*>(d_hi);
-    s->dev.grp_lanes = G; s->dev.grp_top = (int32_t)levels.size() - 1; s->dev.grp_total = off;
     return RT_OK;
 }
 
@@ -1050,17 +979,13 @@ rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_sce
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         e = hipStreamCreateWithPriority(&s->tier_stream, hipStreamNonBlocking, prio_hi);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s->group_stream, hipStreamNonBlocking, prio_hi);
         for (int k = 0; k < 4 && e == hipSuccess; ++k) {
             e = hipEventCreateWithFlags(&s->ev_fork[k], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join[k], hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_gjoin[k], hipEventDisableTiming);
         }
         if (e != hipSuccess) { g_last_hip_error = (int)e; g_detail = "creating the tier stream failed"; rt_scene_destroy(s); return RT_ERR_HIP; }
     }
     st = build_tier_data(s, d);
-    if (st != RT_OK) { rt_scene_destroy(s); return st; }
-    st = build_group_tree(s, d);
     if (st != RT_OK) { rt_scene_destroy(s); return st; }
     st = build_walk(s, d);
     if (st != RT_OK) { rt_scene_destroy(s); return st; }
@@ -1297,17 +1222,23 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     size_t tier_lds = 0;
     unsigned tier_grid = 0;
     int tier_waves_per_main_wg = 0;
+    bool tier_big = false;                       // the 256-register variant of the general tier kernel
     fp.tier_lds_scene = 0;
-    if (kernel == RT_KERNEL_STAGED && g_opt.tier_kernel && s->dev.leaf_lo != nullptr && g_opt.tier1_pixels > 0) {
+    // (not for scenes scanned in lockstep, lds_mode 4: a handful of leaves, every pixel about as dear as the next -- the Cornell
+    // box's 1/8 share measured 182 ms without it and 199 ms with it, profiles/r03_general_defaults.log)
+    if (kernel == RT_KERNEL_STAGED && g_opt.tier_kernel && lds_mode != 4 && s->dev.leaf_lo != nullptr && g_opt.tier1_pixels > 0) {
         size_t budget;
         if (lean_family) {
             const size_t used = (size_t)per_cu_resident * (lds_bytes + 512);
             budget = g_lds_per_cu > used + 1024 ? g_lds_per_cu - used - 1024 : 0;
         } else {
-            budget = g_lds_per_cu / (size_t)per_cu_resident - 1024;                  // the slot of one main workgroup ...
-            const size_t per_tier_wg = budget / (block.x / RT_TIER_THREADS > 0 ? block.x / RT_TIER_THREADS : 1);
-            budget = per_tier_wg;                                                    // ... shared by the tier workgroups it holds
-            tier_waves_per_main_wg = (int)(block.x / 64u);
+            // the slot of one main workgroup, shared by the tier workgroups it holds: as many as it has groups of four waves --
+            // or, where a main workgroup has the CU to itself (768 threads: 3 x 168 registers per SIMD), two tier workgroups of
+            // the 256-register variant, which does not spill
+            tier_big = per_cu_resident == 1 && block.x >= 768;
+            const unsigned tier_wgs_per_slot = tier_big ? 2u : (block.x / RT_TIER_THREADS > 0 ? block.x / RT_TIER_THREADS : 1u);
+            budget = (g_lds_per_cu / (size_t)per_cu_resident - 1024) / tier_wgs_per_slot;
+            tier_waves_per_main_wg = (int)(tier_wgs_per_slot * (RT_TIER_THREADS / 64));
         }
         const int ns_ = s->dev.n_slots, nsph = s->dev.n_spheres, nm = s->dev.n_materials, nt = s->dev.n_textures;
         if (rt_tier_lds_bytes(ns_, nsph, nm, nt, false) <= budget) {
@@ -1316,27 +1247,8 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             tier_lds = rt_tier_lds_bytes(ns_, nsph, nm, nt, fp.tier_lds_scene != 0);
             // the tier kernel's grid is fixed before the ranking has sized the tier: what can be resident beside the main
             // grid (one workgroup per CU) and as much again queued behind it; workgroups beyond the tier's size leave at once
-            tier_grid = lean_family ? (unsigned)(2 * g_num_cu) : (unsigned)(g_num_cu * per_cu_resident) * (block.x / RT_TIER_THREADS > 0 ? block.x / RT_TIER_THREADS : 1u) / 2u;
+            tier_grid = lean_family ? (unsigned)(2 * g_num_cu) : (unsigned)(g_num_cu * per_cu_resident) * (unsigned)(tier_waves_per_main_wg / (RT_TIER_THREADS / 64)) / 2u;
             if (tier_grid < 1u) tier_grid = 1u;
-        }
-    }
-    // ---- the group kernel of ranked launches (rt_kernel_group.h): tier 2, 64 / G pixels per wave.  Lean family only: like a
-    // tier workgroup a group workgroup (four waves, <= 128 VGPRs) is resident beside a full main grid; a CU's spare registers
-    // hold one such wave per SIMD, so a CU hosts a tier workgroup OR a group workgroup next to its two main workgroups.
-    bool group_possible = false;
-    size_t group_lds = 0;
-    unsigned group_grid = 0;
-    fp.group_lds_scene = 0;
-    if (kernel == RT_KERNEL_STAGED && g_opt.group_kernel && lean_family && s->dev.grp_lo != nullptr && g_opt.sparse_stride > 0) {
-        const size_t used = (size_t)per_cu_resident * (lds_bytes + 512);
-        const size_t budget = g_lds_per_cu > used + 1024 ? g_lds_per_cu - used - 1024 : 0;
-        const size_t tree = (size_t)s->dev.grp_total * 32;
-        const size_t scene = s->sphere_bytes + s->shade_bytes;
-        if (tree <= budget) {
-            group_possible = true;
-            if (tree + scene <= budget) fp.group_lds_scene = 1;
-            group_lds = tree + (fp.group_lds_scene ? scene : 0);
-            group_grid = (unsigned)(2 * g_num_cu);
         }
     }
     out.kernel_variant = kernel * 1000 + lds_mode * 100 + s->tex_level * 10 + (s->spheres_only ? 1 : 0);
@@ -1376,19 +1288,11 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             HIPCHK(hipEventRecord(s->ev_fork[pi], stream));
             HIPCHK(hipStreamWaitEvent(s->tier_stream, s->ev_fork[pi], 0));
             HIPCHK(s->spheres_only ? rt_launch_tier_spheres(s->tex_level, s->dev, q, dim3(tier_grid), tier_lds, s->tier_stream)
-                                   : rt_launch_tier_general(s->tex_level, s->need_uv, s->dev, q, dim3(tier_grid), tier_lds, s->tier_stream));
+                                   : rt_launch_tier_general(s->tex_level, s->need_uv, tier_big, s->dev, q, dim3(tier_grid), tier_lds, s->tier_stream));
             HIPCHK(hipEventRecord(s->ev_join[pi], s->tier_stream));
-        }
-        const bool groups = ranked && group_possible;
-        if (groups) {
-            if (!tiers) HIPCHK(hipEventRecord(s->ev_fork[pi], stream));
-            HIPCHK(hipStreamWaitEvent(s->group_stream, s->ev_fork[pi], 0));
-            HIPCHK(rt_launch_group_spheres(s->tex_level, s->dev.grp_lanes, s->dev, q, dim3(group_grid), group_lds, s->group_stream));
-            HIPCHK(hipEventRecord(s->ev_gjoin[pi], s->group_stream));
         }
         HIPCHK(launch_render(kernel, lds_mode, s, q, grid_q, block, lds_bytes, stream));
         if (tiers) HIPCHK(hipStreamWaitEvent(stream, s->ev_join[pi], 0));
-        if (groups) HIPCHK(hipStreamWaitEvent(stream, s->ev_gjoin[pi], 0));
         return RT_OK;
     };
     if (g_opt.lpt && kernel == RT_KERNEL_STAGED && f->ns >= 2 * g_opt.split_samples && n_tiles >= 64 && n_pixels < (1ull << 31)) {
@@ -1421,7 +1325,12 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
                 // keyed by pixels per resident lane (the 1200x800 frame: 3.7 whole, 1.8 / 0.9 / 0.5 for a half, a quarter,
                 // an eighth; a quarter of 1920x1080 is 2.0): what matters is how empty the machine is, not the fraction
                 const double per_lane = (double)n_pixels / ((double)max_grid * (double)block.x);
-                if (per_lane > 2.75) { /* the defaults */ }
+                if (per_lane > 2.75) {
+                    // whole frames.  Lean family: the defaults.  The others: a tier wave is a main workgroup's slot taken away and
+                    // their dear pixels are many and alike (Book-2 final: the fog ball), so only the very dearest get one
+                    // (Book-2 final 800x800 @ 200: 352 ms with the lean sizes, 342 ms with these, profiles/r03_general_defaults.log)
+                    if (!lean_family) { e_tier1_factor = 70; e_tier1_pixels = 256; e_tier1_depth = 1; }
+                }
                 else if (per_lane > 1.375) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; }
                 else if (per_lane > 0.6875) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; e_work_percent = 20; }
                 else { e_tier1_pixels = 8192; e_tier1_factor = 20; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 15; e_sparse_percent = 80; e_work_percent = 40; }
@@ -1434,15 +1343,12 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             rp.max_grid = max_grid; rp.waves_per_wg = block.x / 64u;
             rp.normal_need = (uint32_t)((q.work_items + block.x - 1) / block.x);
             rp.sparse_stride = (g_opt.sparse_stride > 0 && block.x >= 64) ? g_opt.sparse_stride : 0;
-            rp.semi_stride = g_opt.semi_stride;
+            rp.semi_stride = g_opt.semi_stride >= 0 ? g_opt.semi_stride : (lean_family ? 1 : 0);
             rp.sparse_percent = e_sparse_percent;
             rp.sparse_work_percent = e_work_percent;
             rp.tier_possible = tier_possible ? 1 : 0;
             rp.tier1_pixels = e_tier1_pixels; rp.tier1_depth = e_tier1_depth;
             rp.tier_wgs_cap = (int32_t)tier_grid; rp.tier_waves_per_main_wg = tier_waves_per_main_wg;
-            rp.group_wgs_cap = group_possible ? (int32_t)group_grid : 0;
-            rp.group_pixels_per_wg = (RT_TIER_THREADS / 64) * (64 / (s->dev.grp_lanes > 0 ? s->dev.grp_lanes : 8));
-            rp.group_depth = g_opt.group_depth;
             rp.nx = f->nx; rp.smooth_percent = g_opt.cost_smooth_percent;
             if (e_sparse_factor < e_heavy_factor) e_sparse_factor = e_heavy_factor;
             rp.heavy_factor = (float)e_heavy_factor / 10.0f; rp.sparse_factor = (float)e_sparse_factor / 10.0f; rp.tier1_factor = (float)e_tier1_factor / 10.0f;

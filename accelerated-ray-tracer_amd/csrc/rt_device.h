@@ -49,7 +49,6 @@ struct rt_rank_info {
     uint32_t tier2_items;        // following entries served by sparse waves (tier 2); the REST of the list (tier 3) is taken by
                                  // ordinary lanes before anything else, so that every dear pixel's chain starts at once
     int32_t tier1_wgs;           // workgroups of the TIER kernel that have work (the rest of its grid leaves at once)
-    int32_t group_wgs;           // workgroups of the GROUP kernel that have work; when > 0 it serves tier 2 and no main workgroup starts sparse
     int32_t main_skip_wgs;       // workgroups [0, main_skip_wgs) of the MAIN kernel leave at once: their slots are the tier
                                  // kernel's (kernel families whose register budget leaves no room beside a full main grid)
     int32_t sparse_wgs;          // main workgroups [main_skip_wgs, main_skip_wgs + sparse_wgs) start in sparse mode (tier 2)
@@ -80,9 +79,6 @@ struct rt_rank_params {
     int32_t tier1_pixels;                // cap on tier 1
     int32_t tier1_depth;                 // pixels a tier-1 wave is meant to take, one after the other
     int32_t tier_wgs_cap;                // the tier kernel's grid (fixed on the host before the sizes are known)
-    int32_t group_wgs_cap;               // the group kernel's grid; 0 = no group kernel (tier 2 on sparse main workgroups)
-    int32_t group_pixels_per_wg;         // pixels a group workgroup holds at a time (waves x 64 / lanes per pixel)
-    int32_t group_depth;                 // pixels a group is meant to take, one after the other
     int32_t tier_waves_per_main_wg;      // 0: tier workgroups fit beside a full main grid; else: tier waves that fit into the
                                          // slot of one main workgroup (main_skip_wgs = tier waves / this, rounded up)
     int32_t nx, smooth_percent;          // cost estimate of a pixel = max(own, smooth_percent % of its dearest 4-neighbour's); nx = pixels per local row
@@ -119,14 +115,6 @@ struct rt_scene_dev {
     int32_t n_leaves, n_slots;
     int32_t n_media_leaves;
     int32_t media_ord[2];
-    // group tree (rt_kernel_group.h; null / grp_lanes = 0 when the scene has none): a G-ary hierarchy of union boxes over the
-    // same leaf sequence, G = grp_lanes.  Level 0 = the leaves, level k + 1 = the unions of G consecutive level-k boxes, up to
-    // level grp_top which has at most G boxes; every level padded to a multiple of G.  One entry = lo (bmin, prim as int bits
-    // at level 0) + hi (bmax, 1.0f = entry present / 0.0f = padding); level k starts at entry grp_off[k].
-    const float4* grp_lo;
-    const float4* grp_hi;
-    int32_t grp_lanes, grp_top, grp_total;
-    int32_t grp_off[4];
     rt_camera camera;
 };
 
@@ -148,7 +136,6 @@ struct rt_frame_params {
     const rt_rank_info* rank;             // ranked launches: tier sizes left by the ranking kernels; null = no heavy list, no tiers
     int32_t fresh;                        // ranked FIRST part (tiers from the cost prior): state_in only carries the prior's cost and
                                           // list flag; pixels start from their seed with an empty colour sum
-    int32_t group_lds_scene;              // group kernel: the same for its image (group tree + spheres, materials, textures)
     int32_t tier_lds_scene;               // tier kernel: its LDS image holds spheres, materials and textures besides the leaf arrays
     uint64_t seed_base;
     int32_t nx, ny, ns;
@@ -206,8 +193,6 @@ hipError_t rt_launch_staged_general(int lds_mode, const rt_scene_dev& sd, const 
                                     size_t lds, hipStream_t st);
 hipError_t rt_launch_staged_general_tex(int lds_mode, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, dim3 block,
                                         size_t lds, hipStream_t st);
-// the group kernel of a ranked launch (rt_group_spheres.hip): tier 2, several pixels per wave in lockstep
-hipError_t rt_launch_group_spheres(int tex_level, int lanes, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st);
 // the tier kernel of a ranked launch (rt_tier_*.hip); *vgprs_out (optional) = the instantiation's register count
 hipError_t rt_launch_tier_spheres(int tex_level, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st);
-hipError_t rt_launch_tier_general(int tex_level, bool need_uv, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st);
+hipError_t rt_launch_tier_general(int tex_level, bool need_uv, bool big, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st);

@@ -161,36 +161,6 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
             // keeps the latency of a wave's last few live lanes near one node step per step (end of frame, small
             // multi-GPU partitions); checking every other step halves the loop's scalar overhead
             const int trip_pairs = ((sparse ? 2 * fp.steps_per_trip : fp.steps_per_trip) + RT_STEP_UNROLL - 1) / RT_STEP_UNROLL;
-#ifdef RT_PREFETCH
-            // Experiment (round 3): the record of BOTH possible next nodes -- node + 1 (box passes at an
-            // interior node) and the skip target -- is requested as soon as the current record has arrived, before the slab
-            // test, so that the LDS round trip of the next step overlaps the arithmetic of this one.
-            float4 ca = make_float4(0, 0, 0, 0), cb = ca;
-            if ((unsigned)node < (unsigned)n_nodes) { ca = nodes4[2 * node]; cb = nodes4[2 * node + 1]; }
-            for (int pair = 0; pair < trip_pairs; ++pair) {
-                if (__ballot((unsigned)node < (unsigned)n_nodes) == 0ull) break;
-#pragma unroll
-                for (int half = 0; half < RT_STEP_UNROLL; ++half) {
-                    DIAG_ADD(1, 1); DIAG_ADD(2, __popcll(__ballot((unsigned)node < (unsigned)n_nodes)));
-                    if ((unsigned)node < (unsigned)n_nodes) {
-                        const float4 a = ca, b = cb;
-                        const int32_t link = __float_as_int(b.w), nskip = __float_as_int(a.w);
-                        const int i_pass = node + 1 < n_nodes ? node + 1 : node, i_skip = ~nskip < n_nodes ? ~nskip : node;   // (an index past the end is never followed)
-                        const float4 pa = nodes4[2 * i_pass], pb = nodes4[2 * i_pass + 1];
-                        const float4 sa = nodes4[2 * i_skip], sb = nodes4[2 * i_skip + 1];
-                        const bool pass = slab_test_finite(a, b, cur.o, inv, tmin, best.t);
-                        const bool at_leaf = pass && link >= 0;
-                        const bool stop = at_leaf && pend >= 0;
-                        const bool down = pass && link < 0;
-                        const int next = ~(down ? link : nskip);
-                        pend = (at_leaf && pend < 0) ? node : pend;
-                        parked = stop ? node : parked;
-                        node = stop ? nskip : next;
-                        ca = down ? pa : sa; cb = down ? pb : sb;
-                    }
-                }
-            }
-#else
             for (int pair = 0; pair < trip_pairs; ++pair) {
                 if (__ballot((unsigned)node < (unsigned)n_nodes) == 0ull) break;
 #pragma unroll
@@ -212,7 +182,6 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                     }
                 }
             }
-#endif
         } else {   // a lane's ray has a zero direction component: the reference's own slab form for this trip
             for (int step = 0; step < fp.steps_per_trip; ++step) {
                 if (__ballot((unsigned)node < (unsigned)n_nodes) == 0ull) break;

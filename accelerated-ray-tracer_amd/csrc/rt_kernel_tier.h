@@ -65,11 +65,13 @@ template <bool SPHERES_ONLY>
 DEV bool trace_wave(const TierView& tv, const SceneView& sc, const Ray& r, HitInfo& best) {
     const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     const float tmin = 0.001f;
-    if (!inv_is_finite(inv)) return trace<SPHERES_ONLY>(sc, r, best);   // wave-uniform
     const float a = dot(r.d, r.d);
     const int lane = (int)(threadIdx.x & 63u);
+    // a zero direction component (wave-uniform), or -- found below -- a grazing hit at or before its own box's entry: the
+    // reference's walk decides (one call site at the end: the walk and everything it inlines exist once in the ray loop)
+    const bool finite = inv_is_finite(inv);
     bool meets = false;
-    if (lane < tv.n_slots) {
+    if (finite && lane < tv.n_slots) {
         const float* q = tv.ranges + lane * 8;
         float t_enter, t_exit;
         slab_interval(make_float4(q[0], q[1], q[2], 0.f), make_float4(q[3], q[4], q[5], 0.f), r.o, inv, tmin, t_enter, t_exit);
@@ -82,6 +84,48 @@ DEV bool trace_wave(const TierView& tv, const SceneView& sc, const Ray& r, HitIn
     int32_t bleaf = -1, binst = -1;
     bool bincl = false, anomaly = false;
     float pre0 = FLT_MAX, pre1 = FLT_MAX;          // min t of this lane's candidates below medium 0's / medium 1's ordinal
+    if (SPHERES_ONLY) {
+        // Spheres only: the record is the minimum of (t, ordinal) whatever the order of the tests, so the box tests of all
+        // surviving slots run first -- two slots per LDS round trip -- and every lane notes the (at most two; more: tested on
+        // the spot) leaves whose box passes; the sphere tests then run once or twice for the whole wave instead of once per
+        // slot that has a passing lane.
+        int np = 0;
+        int32_t p0 = -1, p1 = -1;
+        int o0 = 0, o1 = 0;
+        float e0 = 0.f, e1 = 0.f;
+        auto sphere_candidate = [&](int32_t prim, int ord, float t_enter) {
+            float t;
+            if (sphere_test_a(sc.spheres[RT_PRIM_INDEX(prim)], r, a, tmin, FLT_MAX, t)) {
+                if (!(t > t_enter)) anomaly = true;
+                if (t < bt || (t == bt && ord < bord)) { bt = t; bord = ord; bleaf = prim; }
+            }
+        };
+        auto note = [&](bool pass, int32_t prim, int ord, float t_enter) {
+            const bool overflow = pass && np >= 2;
+            if (pass && np == 0) { p0 = prim; o0 = ord; e0 = t_enter; }
+            if (pass && np == 1) { p1 = prim; o1 = ord; e1 = t_enter; }
+            if (pass) ++np;
+            if (__ballot(overflow) != 0ull) { if (overflow) sphere_candidate(prim, ord, t_enter); }
+        };
+        while (slot_mask != 0ull) {
+            const int k0 = __ffsll((long long)slot_mask) - 1;
+            slot_mask &= slot_mask - 1ull;
+            const bool two = slot_mask != 0ull;                       // wave-uniform
+            const int k1 = two ? __ffsll((long long)slot_mask) - 1 : k0;
+            if (two) slot_mask &= slot_mask - 1ull;
+            const int ord0 = k0 * 64 + lane, ord1 = k1 * 64 + lane;
+            const float4 lo0 = tv.lo[ord0], hi0 = tv.hi[ord0], lo1 = tv.lo[ord1], hi1 = tv.hi[ord1];
+            float t_enter, t_exit;
+            slab_interval(lo0, hi0, r.o, inv, tmin, t_enter, t_exit);
+            note(__float_as_int(lo0.w) >= 0 && !(t_exit <= t_enter), __float_as_int(lo0.w), ord0, t_enter);
+            if (two) {
+                slab_interval(lo1, hi1, r.o, inv, tmin, t_enter, t_exit);
+                note(__float_as_int(lo1.w) >= 0 && !(t_exit <= t_enter), __float_as_int(lo1.w), ord1, t_enter);
+            }
+        }
+        if (__ballot(np >= 1) != 0ull) { if (np >= 1) sphere_candidate(p0, o0, e0); }
+        if (__ballot(np >= 2) != 0ull) { if (np >= 2) sphere_candidate(p1, o1, e1); }
+    } else
     while (slot_mask != 0ull) {                    // ascending slots: a lane meets its leaves in ordinal order
         const int k = __ffsll((long long)slot_mask) - 1;
         slot_mask &= slot_mask - 1ull;
@@ -110,7 +154,7 @@ DEV bool trace_wave(const TierView& tv, const SceneView& sc, const Ray& r, HitIn
             }
         }
     }
-    if (__ballot(anomaly) != 0ull) return trace<SPHERES_ONLY>(sc, r, best);   // a grazing hit at or before its box's entry: the reference's walk decides
+    if (!finite || __ballot(anomaly) != 0ull) return trace<SPHERES_ONLY>(sc, r, best);
     // ---- media, in ordinal order, each against the limit the reference has when it gets there (wave-uniform values)
     float tm[2] = {FLT_MAX, FLT_MAX};
     bool hm[2] = {false, false};
@@ -168,8 +212,11 @@ DEV bool trace_wave(const TierView& tv, const SceneView& sc, const Ray& r, HitIn
 
 // LDS_SCENE: the workgroup's LDS image also holds the spheres, materials and textures (a template parameter, not a run-time
 // flag, so that those reads are LDS instructions and not flat loads through a pointer of unknown address space)
-template <bool SPHERES_ONLY, int TEX, bool NEED_UV, bool LDS_SCENE>
-__global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4 : 3) rt_tier_kernel(rt_scene_dev sd, rt_frame_params fp) {
+// BIG: a 256-register budget (two waves per SIMD) for the general families where a main workgroup has a CU to itself (Book-2
+// final: 768 threads): the slot one of them vacates then holds two tier workgroups.  At the 168 registers of a 256-thread main
+// workgroup's slot the general variants spill 208-224 B per lane; at 218 they spill nothing (profiles/r03_kernel_resources.md).
+template <bool SPHERES_ONLY, int TEX, bool NEED_UV, bool LDS_SCENE, bool BIG = false>
+__global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4 : (BIG ? 2 : 3)) rt_tier_kernel(rt_scene_dev sd, rt_frame_params fp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const rt_rank_info* q = fp.rank;
     const int my_wgs = q->tier1_wgs;
@@ -297,16 +344,16 @@ __global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4
 #endif
 }
 
-template <bool SO, int TX, bool UV, bool LS>
+template <bool SO, int TX, bool UV, bool LS, bool BIG>
 static hipError_t rt_launch_tier_variant(const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st) {
     if (lds > 65536) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_tier_kernel<SO, TX, UV, LS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_tier_kernel<SO, TX, UV, LS, BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((rt_tier_kernel<SO, TX, UV, LS>), grid, dim3(RT_TIER_THREADS), lds, st, sd, fp);
+    hipLaunchKernelGGL((rt_tier_kernel<SO, TX, UV, LS, BIG>), grid, dim3(RT_TIER_THREADS), lds, st, sd, fp);
     return hipGetLastError();
 }
-template <bool SO, int TX, bool UV>
+template <bool SO, int TX, bool UV, bool BIG = false>
 static hipError_t rt_launch_tier_one(const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st) {
-    return fp.tier_lds_scene ? rt_launch_tier_variant<SO, TX, UV, true>(sd, fp, grid, lds, st) : rt_launch_tier_variant<SO, TX, UV, false>(sd, fp, grid, lds, st);
+    return fp.tier_lds_scene ? rt_launch_tier_variant<SO, TX, UV, true, BIG>(sd, fp, grid, lds, st) : rt_launch_tier_variant<SO, TX, UV, false, BIG>(sd, fp, grid, lds, st);
 }

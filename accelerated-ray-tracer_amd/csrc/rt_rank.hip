@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_tiles_kernel(rt_rank_par
         const double mean = (double)*rp.ray_counter / (double)rp.n_pixels;
         rt_rank_info inf;
         inf.heavy_items = 0u; inf.heavy_threshold = 0xFFFFFFFFu; inf.tier1_items = 0u; inf.tier2_items = 0u;
-        inf.tier1_wgs = 0; inf.group_wgs = 0; inf.main_skip_wgs = 0; inf.sparse_wgs = 0; inf.sparse_stride = 1; inf.semi_wgs = 0; inf.semi_stride = 1;
+        inf.tier1_wgs = 0; inf.main_skip_wgs = 0; inf.sparse_wgs = 0; inf.sparse_stride = 1; inf.semi_wgs = 0; inf.semi_stride = 1;
         inf.threshold1 = (unsigned int)(mean * (double)rp.tier1_factor + 0.999);
         inf.threshold2 = (unsigned int)(mean * (double)rp.sparse_factor + 0.999);
         inf.collected = 0u;
@@ -182,19 +182,10 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
     // tier 2 = what is left of the pixels at or above the sparse threshold; tier 3 = the rest of the list
     unsigned int tier2_items = n_tier2 > tier1_items ? n_tier2 - tier1_items : 0u;
     if (tier1_items + tier2_items > count) tier2_items = count - tier1_items;
-    unsigned int tier2_wgs = 0u, group_wgs = 0u;
-    if (rp.group_wgs_cap > 0) {
-        // tier 2 on the group kernel (rt_kernel_group.h): its groups take their pixels one after the other, group_depth of them
-        // on average; no main workgroup starts sparse
-        const unsigned int per = (unsigned int)rp.group_pixels_per_wg * (rp.group_depth > 0 ? (unsigned int)rp.group_depth : 1u);
-        group_wgs = (tier2_items + per - 1u) / per;
-        if (group_wgs > (unsigned int)rp.group_wgs_cap) group_wgs = (unsigned int)rp.group_wgs_cap;
-    } else {
-        const unsigned int per_wg2 = rp.waves_per_wg * (64u / (unsigned int)rp.sparse_stride);
-        tier2_wgs = (tier2_items + per_wg2 - 1u) / per_wg2;
-        if (tier2_wgs > cap_wgs) tier2_wgs = cap_wgs;
-        if (tier2_items > tier2_wgs * per_wg2) tier2_items = tier2_wgs * per_wg2;   // what the sparse workgroups cannot hold at once joins tier 3
-    }
+    const unsigned int per_wg2 = rp.waves_per_wg * (64u / (unsigned int)rp.sparse_stride);
+    unsigned int tier2_wgs = (tier2_items + per_wg2 - 1u) / per_wg2;
+    if (tier2_wgs > cap_wgs) tier2_wgs = cap_wgs;
+    if (tier2_items > tier2_wgs * per_wg2) tier2_items = tier2_wgs * per_wg2;   // what the sparse workgroups cannot hold at once joins tier 3
     const unsigned int sparse_wgs = tier2_wgs;
     // tier 3 on workgroups of their own with every semi_stride-th lane live (a lane's rays advance faster the fewer lanes
     // its wave has), as many as hold the whole tier at once
@@ -221,7 +212,7 @@ __global__ void __launch_bounds__(RANK_THREADS) rt_rank_heavy_kernel(rt_rank_par
     if (total > sparse_wgs + semi_wgs) {
         inf.semi_wgs = (int32_t)semi_wgs; inf.semi_stride = rp.semi_stride > 0 ? rp.semi_stride : 1;
         inf.heavy_items = count; inf.tier1_items = tier1_items; inf.tier2_items = tier2_items;
-        inf.tier1_wgs = (int32_t)tier1_wgs; inf.group_wgs = (int32_t)group_wgs; inf.main_skip_wgs = (int32_t)skip; inf.sparse_wgs = (int32_t)sparse_wgs;
+        inf.tier1_wgs = (int32_t)tier1_wgs; inf.main_skip_wgs = (int32_t)skip; inf.sparse_wgs = (int32_t)sparse_wgs;
         inf.sparse_stride = rp.sparse_stride;
     } else {
         inf.heavy_items = 0u; inf.heavy_threshold = 0xFFFFFFFFu;

@@ -199,11 +199,6 @@ def test_scheduling_knobs_do_not_change_pixels(gpu):
                 (3, {"sparse_stride": 2, "heavy_factor_x10": 12, "sparse_priority": 0, "sparse_eager": 1}), (3, {"tier1_pixels": 0, "sparse_stride": 16}),
                 (3, {"split_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 4096}), (3, {"split_samples": 3, "tier1_factor_x10": 15}),
                 (3, {"split_samples": 3, "presplit_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 12}), (3, {"split_samples": 2, "presplit_samples": 1, "tier1_pixels": 0}),
-                # tier 2 on the group kernel (8 / 16 lanes per pixel, one pixel after the other per group or many), and back on sparse waves
-                (3, {"split_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 10, "tier1_pixels": 0, "sparse_work_percent": 100}),
-                (3, {"split_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 10, "tier1_pixels": 0, "sparse_work_percent": 100, "group_lanes": 16, "group_depth": 8}),
-                (3, {"split_samples": 3, "presplit_samples": 1, "heavy_factor_x10": 10, "sparse_factor_x10": 12, "tier1_factor_x10": 30, "sparse_work_percent": 100, "group_depth": 1}),
-                (3, {"split_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 10, "tier1_pixels": 0, "sparse_work_percent": 100, "group_kernel": 0}),
                 # the tier kernel off (tier 1 empty), the cost prior off (an unranked first part), both
                 (3, {"split_samples": 3, "tier_kernel": 0, "heavy_factor_x10": 10}), (3, {"split_samples": 2, "prior": 0}), (3, {"split_samples": 2, "presplit_samples": 1, "prior": 0, "tier_kernel": 0, "heavy_factor_x10": 10}),
                 (3, {"split_samples": 3, "presplit_samples": 1, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 8192, "tier1_depth": 1}),
@@ -351,9 +346,6 @@ def test_split_frame_schedule_matches_oracle(gpu, orc, name, nx, ny, ns):
                  # every pixel on the tier kernel (list from 1.0 x the mean, no cap to speak of), one pixel per wave and several
                  {"split_samples": 4, "presplit_samples": 2, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 65536, "tier1_depth": 1, "sparse_work_percent": 100},
                  {"split_samples": 2, "heavy_factor_x10": 10, "tier1_factor_x10": 10, "tier1_pixels": 65536, "tier1_depth": 16, "sparse_work_percent": 100, "threads": 256, "wg_per_cu": 3},
-                 # every listed pixel on the group kernel (spheres-only scenes; elsewhere: sparse waves), 8 and 16 lanes per pixel
-                 {"split_samples": 4, "presplit_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 10, "tier1_pixels": 0, "sparse_work_percent": 100, "group_depth": 1},
-                 {"split_samples": 2, "heavy_factor_x10": 10, "sparse_factor_x10": 10, "tier1_factor_x10": 40, "sparse_work_percent": 100, "group_lanes": 16, "group_depth": 4},
                  # without the cost prior (unranked first part), without the tier kernel
                  {"split_samples": 4, "presplit_samples": 2, "prior": 0, "heavy_factor_x10": 12, "tier1_factor_x10": 15, "tier1_pixels": 4096},
                  {"split_samples": 4, "tier_kernel": 0, "heavy_factor_x10": 12}):

@@ -14,10 +14,15 @@ def short(n):
         if key in n: return s
     return n[:40]
 # frames are separated by gaps; a frame starts at a "prior" kernel (or the first main kernel after a long gap)
+# the last frame: from its cost-prior kernel on, or -- without the prior -- from the third-last main-kernel launch (a split
+# frame is three of them) and the buffer fills in front of it
 starts = [i for i, r in enumerate(rows) if short(r[2]) == "prior"]
-if not starts:   # no cost prior: a frame starts at the first render kernel after a pause of the device (> 2 ms)
-    starts = [i for i, r in enumerate(rows) if short(r[2]) in ("main", "tier") and (i == 0 or r[0] - max(x[1] for x in rows[:i]) > 2_000_000)]
-i0 = starts[-1]
+if starts:
+    i0 = starts[-1]
+else:
+    mains = [i for i, r in enumerate(rows) if short(r[2]) == "main"]
+    i0 = mains[-3] if len(mains) >= 3 else mains[0]
+    while i0 > 0 and "fillBuffer" in rows[i0 - 1][2]: i0 -= 1
 t0 = rows[i0][0]
 print(f"{'kernel':12s} {'start ms':>9s} {'end ms':>9s} {'dur ms':>9s}  grid x wg   vgpr scratch lds")
 for s, e, n, wg, grid, vg, sc, lds in rows[i0:]:
