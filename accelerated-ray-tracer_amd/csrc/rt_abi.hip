@@ -40,7 +40,8 @@ struct rt_options {
     int kernel = RT_KERNEL_STAGED;
     int lds_mode = -1;          // -1 = choose from the scene size
     int steps_per_trip = 12;
-    int shade_threshold = 32;
+    int shade_threshold = 0;     // lanes with a finished walk that trigger stage C; 0 = 32, or 16 where the launch has less than 2.75 pixels per
+                                 // resident lane (a share of a frame: waiting for a stage's quorum costs chain time there; 1/8: 50.0 -> 47.6 ms, 1/4: 62.1 -> 60.2)
     int wg_per_cu = 0;          // workgroups per CU of the staged kernel; 0 = per kernel family (2 x 512 lean, 3 x 256 otherwise)
     int threads = 0;            // workgroup size of the staged kernel; 0 = what the kernel family's register budget calls for
     int leaf_threshold = 8;     // lanes with an object test due that trigger the leaf pass (they keep walking meanwhile)
@@ -66,7 +67,8 @@ struct rt_options {
                                  // lean 1 -- whole waves of tier-3 pixels, which with semi_priority 1 measured 100.2 -> 94.3 ms on the headline
                                  // (profiles/r03_priorities_whole.log) --, the others 0 (Book-2 final 352 -> 388 ms with 1, profiles/r03_general_defaults.log)
     int sparse_priority = 3;
-    int tier_priority = 3;       // s_setprio level of the tier kernel's waves
+    int tier_priority = 1;       // s_setprio level of the tier kernel's waves (1 instead of 3: 80.6 -> 76.3 ms on a half, 70.2 -> 62.7 on a quarter of
+                                 // the headline frame, nothing on the whole frame or an eighth: profiles/r03_share_sweep_pass2.log)
     int semi_priority = 1;       // s_setprio level of the semi workgroups' waves (tier 3 on workgroups of its own)
     int sparse_eager = 0;
     int sparse_work_percent = 5;  // tiers 0-2 hold at most this share of the frame's work (rays so far); dearer-than-average pixels beyond it go to tier 3
@@ -621,7 +623,7 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "threads") { if (value != 0 && (value < 64 || value > 768 || (value % 64))) return invalid("threads: 0 (per kernel family) or a multiple of 64 up to 768 (512 for the lean spheres-only kernels)"); g_opt.threads = value; }
     else if (k == "lds_mode") { if (value < -1 || value > 4) return invalid("lds_mode: -1..4"); g_opt.lds_mode = value; }
     else if (k == "steps_per_trip") { if (value < 1 || value > 64) return invalid("steps_per_trip: 1..64"); g_opt.steps_per_trip = value; }
-    else if (k == "shade_threshold") { if (value < 1 || value > 64) return invalid("shade_threshold: 1..64"); g_opt.shade_threshold = value; }
+    else if (k == "shade_threshold") { if (value < 0 || value > 64) return invalid("shade_threshold: 0 (by the launch's load) or 1..64"); g_opt.shade_threshold = value; }
     else if (k == "wg_per_cu") { if (value < 0 || value > 8) return invalid("wg_per_cu: 0 (per kernel family) .. 8"); g_opt.wg_per_cu = value; }
     else return invalid("unknown option");
     return RT_OK;
@@ -1157,11 +1159,9 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     fp.work_items = (uint32_t)fp.tiles_x * (uint32_t)tiles_y * 64u;
     fp.sparse_priority = g_opt.sparse_priority; fp.sparse_eager = g_opt.sparse_eager; fp.semi_priority = g_opt.semi_priority; fp.tier_priority = g_opt.tier_priority;
     fp.steps_per_trip = g_opt.steps_per_trip;
-    fp.shade_threshold = g_opt.shade_threshold;
     fp.leaf_threshold = g_opt.leaf_threshold;
     fp.diel_threshold = g_opt.diel_threshold;
     fp.box_threshold = g_opt.box_threshold; fp.medium_threshold = g_opt.medium_threshold;
-    fp.newpath_threshold = g_opt.newpath_threshold > 0 ? g_opt.newpath_threshold : (s->spheres_only ? 24 : 8);
 
     // LDS residency: nodes + spheres in every workgroup of a CU if they fit that many times (2 workgroups for the lean
     // spheres-only kernels, 3 otherwise: see the workgroup shapes below), else once (one big workgroup per CU), else nodes only
@@ -1213,6 +1213,14 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         grid = dim3(want < need ? want : need);
         per_cu_resident = per_cu;
     }
+    {   // stage quorums.  In a launch that leaves the machine mostly empty (a small share of a frame) a lane waiting for 32 others
+        // to finish their walks is waiting on the frame's critical path: the quorums are halved there.
+        const double pixels_per_lane = (double)local_rows * (double)f->nx / ((double)g_num_cu * (double)per_cu_resident * (double)block.x);
+        // (lean family: every share of the BASELINE frames -- a whole frame is 3.3 - 3.7; the Cornell box's 1/8 share is slower with them: 172 -> 179 ms)
+        const bool latency_regime = kernel == RT_KERNEL_STAGED && lean_family && pixels_per_lane < 2.75;
+        fp.shade_threshold = g_opt.shade_threshold > 0 ? g_opt.shade_threshold : (latency_regime ? 16 : 32);
+        fp.newpath_threshold = g_opt.newpath_threshold > 0 ? g_opt.newpath_threshold : (s->spheres_only ? (latency_regime ? 12 : 24) : 8);
+    }
     // ---- the tier kernel of ranked launches (rt_kernel_tier.h): its LDS image and where its workgroups find room.
     // Lean family: the main kernel's 4 x 96 registers per SIMD leave 128 free, so ONE tier workgroup (four waves, one per
     // SIMD, <= 128 VGPRs) is resident on a CU beside a full main grid if the LDS left over holds its image.  Other families:
@@ -1222,7 +1230,6 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     size_t tier_lds = 0;
     unsigned tier_grid = 0;
     int tier_waves_per_main_wg = 0;
-    bool tier_big = false;                       // the 256-register variant of the general tier kernel
     fp.tier_lds_scene = 0;
     // (not for scenes scanned in lockstep, lds_mode 4: a handful of leaves, every pixel about as dear as the next -- the Cornell
     // box's 1/8 share measured 182 ms without it and 199 ms with it, profiles/r03_general_defaults.log)
@@ -1232,11 +1239,8 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             const size_t used = (size_t)per_cu_resident * (lds_bytes + 512);
             budget = g_lds_per_cu > used + 1024 ? g_lds_per_cu - used - 1024 : 0;
         } else {
-            // the slot of one main workgroup, shared by the tier workgroups it holds: as many as it has groups of four waves --
-            // or, where a main workgroup has the CU to itself (768 threads: 3 x 168 registers per SIMD), two tier workgroups of
-            // the 256-register variant, which does not spill
-            tier_big = per_cu_resident == 1 && block.x >= 768;
-            const unsigned tier_wgs_per_slot = tier_big ? 2u : (block.x / RT_TIER_THREADS > 0 ? block.x / RT_TIER_THREADS : 1u);
+            // the slot of one main workgroup, shared by the tier workgroups it holds: as many as it has groups of four waves
+            const unsigned tier_wgs_per_slot = block.x / RT_TIER_THREADS > 0 ? block.x / RT_TIER_THREADS : 1u;
             budget = (g_lds_per_cu / (size_t)per_cu_resident - 1024) / tier_wgs_per_slot;
             tier_waves_per_main_wg = (int)(tier_wgs_per_slot * (RT_TIER_THREADS / 64));
         }
@@ -1288,7 +1292,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
             HIPCHK(hipEventRecord(s->ev_fork[pi], stream));
             HIPCHK(hipStreamWaitEvent(s->tier_stream, s->ev_fork[pi], 0));
             HIPCHK(s->spheres_only ? rt_launch_tier_spheres(s->tex_level, s->dev, q, dim3(tier_grid), tier_lds, s->tier_stream)
-                                   : rt_launch_tier_general(s->tex_level, s->need_uv, tier_big, s->dev, q, dim3(tier_grid), tier_lds, s->tier_stream));
+                                   : rt_launch_tier_general(s->tex_level, s->need_uv, s->dev, q, dim3(tier_grid), tier_lds, s->tier_stream));
             HIPCHK(hipEventRecord(s->ev_join[pi], s->tier_stream));
         }
         HIPCHK(launch_render(kernel, lds_mode, s, q, grid_q, block, lds_bytes, stream));
@@ -1331,6 +1335,15 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
                     // (Book-2 final 800x800 @ 200: 352 ms with the lean sizes, 342 ms with these, profiles/r03_general_defaults.log)
                     if (!lean_family) { e_tier1_factor = 70; e_tier1_pixels = 256; e_tier1_depth = 1; }
                 }
+                // shares, lean family: re-fitted in round 3 with the tier kernel beside the main kernel (tools/share_sweep.py on rank 0
+                // of the 1200x800 and 1920x1080 frames, profiles/r03_share_sweep_pass*.log; slowest-rank tables in DESIGN.md section 6)
+                else if (lean_family) {
+                    if (per_lane > 1.375) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 25; e_sparse_percent = 80; }
+                    else if (per_lane > 0.6875) { e_tier1_pixels = 8192; e_tier1_factor = 20; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 20; e_sparse_percent = 80; e_work_percent = 40; }
+                    else { e_tier1_pixels = 16384; e_tier1_factor = 15; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 15; e_sparse_percent = 80; e_work_percent = 60; }
+                }
+                // shares, other families: round 2's sizes (Book-2 final's 1/8 share: 216 ms with these, 236 with the lean family's,
+                // 252 without a tier kernel, profiles/r03_share_sweep_final_eighth.log)
                 else if (per_lane > 1.375) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; }
                 else if (per_lane > 0.6875) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 20; e_sparse_factor = 30; e_sparse_percent = 80; e_work_percent = 20; }
                 else { e_tier1_pixels = 8192; e_tier1_factor = 20; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 15; e_sparse_percent = 80; e_work_percent = 40; }

@@ -195,4 +195,4 @@ hipError_t rt_launch_staged_general_tex(int lds_mode, const rt_scene_dev& sd, co
                                         size_t lds, hipStream_t st);
 // the tier kernel of a ranked launch (rt_tier_*.hip); *vgprs_out (optional) = the instantiation's register count
 hipError_t rt_launch_tier_spheres(int tex_level, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st);
-hipError_t rt_launch_tier_general(int tex_level, bool need_uv, bool big, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st);
+hipError_t rt_launch_tier_general(int tex_level, bool need_uv, const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st);

@@ -212,11 +212,12 @@ DEV bool trace_wave(const TierView& tv, const SceneView& sc, const Ray& r, HitIn
 
 // LDS_SCENE: the workgroup's LDS image also holds the spheres, materials and textures (a template parameter, not a run-time
 // flag, so that those reads are LDS instructions and not flat loads through a pointer of unknown address space)
-// BIG: a 256-register budget (two waves per SIMD) for the general families where a main workgroup has a CU to itself (Book-2
-// final: 768 threads): the slot one of them vacates then holds two tier workgroups.  At the 168 registers of a 256-thread main
-// workgroup's slot the general variants spill 208-224 B per lane; at 218 they spill nothing (profiles/r03_kernel_resources.md).
-template <bool SPHERES_ONLY, int TEX, bool NEED_UV, bool LDS_SCENE, bool BIG = false>
-__global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4 : (BIG ? 2 : 3)) rt_tier_kernel(rt_scene_dev sd, rt_frame_params fp) {
+// Register budgets: 128 for the lean family (co-resident with the main kernel), 168 = the slot of a 256-thread main workgroup
+// for the others.  The general variants spill 208-224 B per lane at 168; a 256-register variant without spills (two instead of
+// three tier workgroups in the slot a 768-thread main workgroup vacates) measured WORSE -- Book-2 final's 1/8 share 236 -> 316 ms,
+// profiles/r03_share_sweep_final_eighth.log: the number of tier waves matters more than their spills -- and was removed.
+template <bool SPHERES_ONLY, int TEX, bool NEED_UV, bool LDS_SCENE>
+__global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4 : 3) rt_tier_kernel(rt_scene_dev sd, rt_frame_params fp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const rt_rank_info* q = fp.rank;
     const int my_wgs = q->tier1_wgs;
@@ -344,16 +345,16 @@ __global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4
 #endif
 }
 
-template <bool SO, int TX, bool UV, bool LS, bool BIG>
+template <bool SO, int TX, bool UV, bool LS>
 static hipError_t rt_launch_tier_variant(const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st) {
     if (lds > 65536) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_tier_kernel<SO, TX, UV, LS, BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_tier_kernel<SO, TX, UV, LS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((rt_tier_kernel<SO, TX, UV, LS, BIG>), grid, dim3(RT_TIER_THREADS), lds, st, sd, fp);
+    hipLaunchKernelGGL((rt_tier_kernel<SO, TX, UV, LS>), grid, dim3(RT_TIER_THREADS), lds, st, sd, fp);
     return hipGetLastError();
 }
-template <bool SO, int TX, bool UV, bool BIG = false>
+template <bool SO, int TX, bool UV>
 static hipError_t rt_launch_tier_one(const rt_scene_dev& sd, const rt_frame_params& fp, dim3 grid, size_t lds, hipStream_t st) {
-    return fp.tier_lds_scene ? rt_launch_tier_variant<SO, TX, UV, true, BIG>(sd, fp, grid, lds, st) : rt_launch_tier_variant<SO, TX, UV, false, BIG>(sd, fp, grid, lds, st);
+    return fp.tier_lds_scene ? rt_launch_tier_variant<SO, TX, UV, true>(sd, fp, grid, lds, st) : rt_launch_tier_variant<SO, TX, UV, false>(sd, fp, grid, lds, st);
 }

@@ -328,7 +328,8 @@ def test_drop_in_executable_writes_the_reference_ppm(gpu, orc, tmp_path):
     assert r.returncode != 0
 
 
-@pytest.mark.parametrize("name,nx,ny,ns", [("bouncing", 160, 96, 16), ("cornell", 96, 96, 12), ("final", 80, 80, 8)])
+@pytest.mark.parametrize("name,nx,ny,ns", [("bouncing", 160, 96, 16), ("cornell", 96, 96, 12), ("cornell_smoke", 96, 96, 12), ("final", 80, 80, 8),
+                                           ("degenerate", 96, 64, 8), ("simple_light", 96, 64, 8)])
 def test_split_frame_schedule_matches_oracle(gpu, orc, name, nx, ny, ns):
     """The cost-aware schedule (frame split at sample boundaries, pixels parked and resumed, heavy pixels on sparse waves
     and on the tier kernel's one-pixel waves: trace_wave over spheres, quads, boxes, instances and media) is scheduling

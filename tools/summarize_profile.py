@@ -15,7 +15,7 @@ if ks:
         print(f"  {name:70s} calls {r['Calls']:>4} total_ns {r['TotalDurationNs']:>12} avg_ns {float(r['AverageNs']):>14.0f} pct {r['Percentage']}")
 kt = find("trace", "*kernel_trace.csv")
 if kt:
-    rows = [r for r in csv.DictReader(open(kt)) if "rt_render" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(kt)) if "rt_render" in r["Kernel_Name"] or "rt_tier" in r["Kernel_Name"]]
     if rows:
         r = rows[-1]
         print("== render kernel launch:", {k: r[k] for k in r if k in ("Kernel_Name","VGPR_Count","Accum_VGPR_Count","SGPR_Count","LDS_Block_Size","Scratch_Size","Workgroup_Size_X","Grid_Size_X")})
@@ -26,8 +26,9 @@ for sub in ("pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_fetch", "pmc_write"):
     if not f: continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "rt_render" not in r["Kernel_Name"]: continue
-        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    print(f"== {sub}: per-dispatch mean over {max((len(v) for v in acc.values()), default=0)} render dispatches")
-    for k, v in acc.items():
-        print(f"  {k:28s} {sum(v)/len(v):>20.0f}")
+        if "rt_render" not in r["Kernel_Name"] and "rt_tier" not in r["Kernel_Name"]: continue
+        which = "tier kernel" if "rt_tier" in r["Kernel_Name"] else "main kernel"
+        acc[(which, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    print(f"== {sub}: per-dispatch mean, by kernel (dispatches: {max((len(v) for v in acc.values()), default=0)})")
+    for (which, k), v in sorted(acc.items()):
+        print(f"  {which:12s} {k:28s} {sum(v)/len(v):>20.0f}   ({len(v)} dispatches)")
