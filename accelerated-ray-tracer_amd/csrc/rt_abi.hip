@@ -963,6 +963,12 @@ rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_sce
     UP(images, d->image_bytes);
 #undef UP
     s->dev.n_nodes_ref = d->n_nodes;
+    for (int c = 0; c < 3; ++c) {   // the scene's coordinate bound per axis (regrouped interior boxes are unions of these: the same bound)
+        float b = 0.0f;
+        for (int i = 0; i < d->n_nodes; ++i) b = fmaxf(b, fmaxf(fabsf(d->nodes[i].bmin[c]), fabsf(d->nodes[i].bmax[c])));
+        s->dev.bound[c] = b;
+    }
+    s->dev.bound_pad = 0.0f;
     s->dev.nodes = s->dev.nodes_ref; s->dev.n_nodes = d->n_nodes;     // until the walk array is built below
     s->dev.n_spheres = d->n_spheres;
     s->dev.n_materials = d->n_materials; s->dev.n_textures = d->n_textures;

@@ -105,6 +105,8 @@ struct rt_scene_dev {
     const rt_texture* textures;
     const uint8_t* images;
     int32_t n_nodes, n_nodes_ref, n_spheres, n_materials, n_textures;
+    float bound[3];              // every box coordinate of the scene lies within +-bound[axis] (the walk loop's widened box test)
+    float bound_pad;
     // tier data (rt_kernel_tier.h; built by rt_scene_create from the walk array, null when the scene has none): the leaves
     // of the walk array in depth-first order as two float4 arrays padded to a multiple of 64 -- leaf_lo[q] = (bmin, prim as
     // int bits; -1 in the padding), leaf_hi[q] = (bmax, 0) --, per 64 leaves the union of their boxes (slot_ranges: 8 floats

@@ -731,4 +731,44 @@ DEV bool slab_test_finite(const float4 lo_skip, const float4 hi_prim, const f3 o
     return !(t_out <= t_in);
 }
 
+// ------------------------------------------------------------------ the walk loop's box test (round 3)
+// The walk may visit a SUPERSET of the boxes the reference enters: interior boxes never change a result and
+// every leaf the walk notes has its own box tested again, exactly, before its object test (stage B of the main kernel).  So
+// inside the walk loop a cheaper test is exact as long as it passes whenever aabb::hit would: the slab bounds as ONE fma each,
+//     (b - o) * x   ->   fma(b, x, -(o * x) -+ e)         (x = 1 / d of that axis, b = the box's lower or upper bound)
+// 6 fma instead of 6 subtractions + 6 multiplications per box.  e is the widening that makes the result an outer bound of the
+// reference's: with u = 2^-24, the reference's value is within 2.01 u |V| of V = (b - o) x (two roundings), the fused one within
+// u (3 |o x| + |b x| + 2 e) of V -+ e (c0 = fl(o x), c = fl(c0 -+ e), one fma), and |V| <= (|b| + |o|) |x|; so
+// e >= 5.1 u |x| (|o| + B) suffices for every box of a scene whose coordinates lie within +-B.  e = 2^-20 |x| (|o| + B) is used
+// (three times that).  The lower bound of an axis gets - e, the upper + e -- which of lo / hi is which depends on the sign of x.
+// Rays for which |x| (|o| + B) could overflow (a direction component below ~1e-27 of the others) take the reference's own
+// form instead, like rays with a zero component (loose_ok() is part of `finite_inv`).  A false pass costs one box step; a NaN
+// cannot occur (no product overflows), so fmin / fmax see numbers only.
+struct LooseRay { f3 clo, chi; };   // per axis: the addend for the box's bmin and for its bmax
+DEV bool loose_ok(const f3 inv, const f3 o, const float* bound) {
+    const float ex = fabsf(inv.x) * (fabsf(o.x) + bound[0]), ey = fabsf(inv.y) * (fabsf(o.y) + bound[1]), ez = fabsf(inv.z) * (fabsf(o.z) + bound[2]);
+    return fmaxf(fmaxf(ex, ey), ez) < 1e30f;
+}
+DEV LooseRay loose_setup(const f3 inv, const f3 o, const float* bound) {
+    const float k = 9.5367431640625e-07f;   // 2^-20
+    const float ex = k * (fabsf(inv.x) * (fabsf(o.x) + bound[0])), ey = k * (fabsf(inv.y) * (fabsf(o.y) + bound[1])), ez = k * (fabsf(inv.z) * (fabsf(o.z) + bound[2]));
+    const float cx = -(o.x * inv.x), cy = -(o.y * inv.y), cz = -(o.z * inv.z);
+    LooseRay r;
+    // x > 0: bmin gives the near bound (- e), bmax the far one (+ e); x < 0: the other way round
+    r.clo = mk3(inv.x < 0.0f ? cx + ex : cx - ex, inv.y < 0.0f ? cy + ey : cy - ey, inv.z < 0.0f ? cz + ez : cz - ez);
+    r.chi = mk3(inv.x < 0.0f ? cx - ex : cx + ex, inv.y < 0.0f ? cy - ey : cy + ey, inv.z < 0.0f ? cz - ez : cz + ez);
+    return r;
+}
+DEV bool slab_test_loose(const float4 lo_skip, const float4 hi_prim, const f3 inv, const LooseRay& lr, float tmin, float tmax) {
+    const float x0 = fmaf(lo_skip.x, inv.x, lr.clo.x), x1 = fmaf(hi_prim.x, inv.x, lr.chi.x);
+    const float y0 = fmaf(lo_skip.y, inv.y, lr.clo.y), y1 = fmaf(hi_prim.y, inv.y, lr.chi.y);
+    const float z0 = fmaf(lo_skip.z, inv.z, lr.clo.z), z1 = fmaf(hi_prim.z, inv.z, lr.chi.z);
+    const float nearx = fminf(x0, x1), farx = fmaxf(x0, x1);
+    const float neary = fminf(y0, y1), fary = fmaxf(y0, y1);
+    const float nearz = fminf(z0, z1), farz = fmaxf(z0, z1);
+    const float t_in = fmaxf(fmaxf(fmaxf(nearx, neary), nearz), tmin);
+    const float t_out = fminf(fminf(fminf(farx, fary), farz), tmax);
+    return !(t_out <= t_in);
+}
+
 }  // namespace

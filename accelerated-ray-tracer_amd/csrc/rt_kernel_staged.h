@@ -161,6 +161,9 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
             // keeps the latency of a wave's last few live lanes near one node step per step (end of frame, small
             // multi-GPU partitions); checking every other step halves the loop's scalar overhead
             const int trip_pairs = ((sparse ? 2 * fp.steps_per_trip : fp.steps_per_trip) + RT_STEP_UNROLL - 1) / RT_STEP_UNROLL;
+            // the loop's box test is the widened one-fma-per-bound form (rt_device_funcs.h, slab_test_loose): a superset of
+            // aabb::hit's passes, which is all the walk needs -- stage B tests every noted leaf's own box again, exactly
+            const LooseRay lr = loose_setup(inv, cur.o, sd.bound);
             for (int pair = 0; pair < trip_pairs; ++pair) {
                 if (__ballot((unsigned)node < (unsigned)n_nodes) == 0ull) break;
 #pragma unroll
@@ -168,7 +171,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                     DIAG_ADD(1, 1); DIAG_ADD(2, __popcll(__ballot((unsigned)node < (unsigned)n_nodes)));
                     if ((unsigned)node < (unsigned)n_nodes) {
                         const float4 a = nodes4[2 * node], b = nodes4[2 * node + 1];
-                        const bool pass = slab_test_finite(a, b, cur.o, inv, tmin, best.t);
+                        const bool pass = slab_test_loose(a, b, inv, lr, tmin, best.t);
                         // device encoding of the links (rt_device.h, RT_NODE_SKIP): a.w = ~skip, b.w = ~(node + 1) for
                         // an interior node and the object id (>= 0) at a leaf -- "where next" is one select and one
                         // NOT, and the stopped form ~skip is a.w as stored
@@ -451,7 +454,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
             DIAG_ADD(12, 1); DIAG_ADD(13, __popcll(__ballot(node == ST_SETUP)));
             if (node == ST_SETUP) {
                 inv = mk3(1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z);
-                finite_inv = inv_is_finite(inv);
+                finite_inv = inv_is_finite(inv) && loose_ok(inv, cur.o, sd.bound);   // (else: the reference's own slab form, leaf by leaf)
                 cur_a = dot(cur.d, cur.d);
                 best.t = FLT_MAX; best.prim = -1; best.inst = -1;
                 node = n_nodes > 0 ? 0 : ST_DONE;

@@ -217,7 +217,7 @@ def host_cores() -> int:
 def cpu_baseline(scene_name: str, nx: int, ny: int, ns: int) -> dict:
     """The oracle (a port of the reference's algorithm, see oracle/) timed on this box's host cores.  One fixed, stated
     configuration: one thread per usable core (affinity mask cut down to the cgroup CPU quota), no probing; the sample is
-    the bench frame at reduced spp, doubled until it is at least 3 s of wall time."""
+    the bench frame at reduced spp (48 spp = ~1e8 rays: 2 - 7 s per run on a 16-cpu share), best of three runs."""
     import oracle
     name = "bouncing" if scene_name == "random_scene" else scene_name
     sc = oracle.OracleScene(name, nx, ny)
@@ -226,16 +226,20 @@ def cpu_baseline(scene_name: str, nx: int, ny: int, ns: int) -> dict:
         logical = len(os.sched_getaffinity(0))
     except AttributeError:
         logical = os.cpu_count() or threads
-    sc.render(1, threads=threads, counters=True)   # page the library and the scene in; not timed
-    while True:
+    sc.render(2, threads=threads, counters=True)   # page the library and the scene in; not timed
+    # The GPU boxes' hosts are shared (256 logical cpus, this job's cgroup quota a fraction of them): the same sample ran 3.8x
+    # apart minutes apart on one box (profiles/r03z_bench_n1*.json of the first pass).  So the sample is timed three times and
+    # the best run is the figure; all three are listed.
+    runs = []
+    for _ in range(3):
         t0 = time.time()
         _, cnt = sc.render(ns, threads=threads, counters=True)
-        dt = time.time() - t0
-        if dt >= 3.0 or ns >= 1024:
-            break
-        ns *= 2
-    return {"value": round(cnt["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{scene_name} {nx}x{ny} @ {ns} spp (same scene/seeds, reduced spp), {cnt['rays']} rays in {dt:.1f} s on {threads} threads = usable cores (cgroup quota / affinity; {logical} logical cpus in the affinity mask, os.cpu_count() = {os.cpu_count()})"}
+        runs.append((cnt["rays"] / (time.time() - t0) / 1e6, time.time() - t0))
+    best = max(r[0] for r in runs)
+    return {"value": round(best, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{scene_name} {nx}x{ny} @ {ns} spp (same scene/seeds, reduced spp), {cnt['rays']} rays, best of three runs "
+                      f"({', '.join(f'{r[0]:.1f} Mrays/s in {r[1]:.1f} s' for r in runs)}) on {threads} threads = usable cores (cgroup quota / affinity; "
+                      f"{logical} logical cpus in the affinity mask, os.cpu_count() = {os.cpu_count()})"}
 
 
 def main():
