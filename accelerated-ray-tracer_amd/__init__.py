@@ -73,6 +73,7 @@ RT_ABI_SYMBOLS = ["rt_init", "rt_shutdown", "rt_strerror", "rt_last_hip_error", 
                   "rt_scene_destroy", "rt_frame_local_rows", "rt_local_to_global_row", "rt_render", "rt_frame_finish",
                   "rt_set_option", "rt_reset_options", "rt_scene_walk_info", "rt_init_devices", "rt_multi_create", "rt_multi_render",
                   "rt_multi_destroy", "rt_multi_device_count", "rt_multi_row_owner", "rt_multi_probe_rccl", "rt_multi_debug_uninterleave",
+                  "rt_progressive_state_create", "rt_progressive_state_destroy", "rt_render_window",
                   "rt_plan_walk_array", "rt_regroup_leaves"]
 
 _rt = None
@@ -136,6 +137,9 @@ def rt_lib():
         L.rt_multi_destroy.argtypes = [C.c_void_p]
         L.rt_multi_device_count.argtypes = [C.c_void_p]
         L.rt_multi_row_owner.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.rt_progressive_state_create.argtypes = [C.c_void_p, C.POINTER(RtFrameDesc), C.POINTER(C.c_void_p)]
+        L.rt_progressive_state_destroy.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_render_window.argtypes = [C.c_void_p, C.POINTER(RtFrameDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.POINTER(RtStats)]
         L.rt_multi_probe_rccl.argtypes = [C.c_char_p]
         L.rt_multi_debug_uninterleave.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         L.rt_plan_walk_array.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
@@ -289,6 +293,10 @@ class DeviceScene:
         _check(L.rt_render(self._p, C.byref(frame), C.c_void_p(int(out)), 1, stream, 1 if blocking else 0, C.byref(stats)), "rt_render")
         return None, stats
 
+    def progressive(self, frame: RtFrameDesc) -> "ProgressiveFrame":
+        """Progressive accumulation of `frame` (rt_render_window): windows of samples, a displayable frame after each."""
+        return ProgressiveFrame(self, frame)
+
     def walk_info(self) -> dict:
         """Node counts of the reference tree / the walk array and expected box tests per ray on the calibration frame."""
         a, b, x, y = C.c_int32(0), C.c_int32(0), C.c_double(0), C.c_double(0)
@@ -303,6 +311,34 @@ class DeviceScene:
     def close(self):
         if self._p:
             rt_lib().rt_scene_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ProgressiveFrame:
+    """rt_progressive_state_* + rt_render_window: the per-pixel XORWOW state and colour sum carried between windows."""
+
+    def __init__(self, scene: DeviceScene, frame: RtFrameDesc):
+        self.scene, self.frame = scene, frame
+        self._p = C.c_void_p()
+        _check(rt_lib().rt_progressive_state_create(scene._p, C.byref(frame), C.byref(self._p)), "rt_progressive_state_create")
+        self.rows = rt_lib().rt_frame_local_rows(C.byref(frame))
+
+    def render(self, sample_begin: int, sample_end: int):
+        """Samples [sample_begin, sample_end) of every pixel; returns (the frame averaged over sample_end samples, stats)."""
+        out = np.empty((self.rows, self.frame.nx, 3), np.float32)
+        stats = RtStats()
+        _check(rt_lib().rt_render_window(self.scene._p, C.byref(self.frame), out.ctypes.data, 0, self._p, sample_begin, sample_end, None, 1, C.byref(stats)), "rt_render_window")
+        return out, stats
+
+    def close(self):
+        if self._p:
+            rt_lib().rt_progressive_state_destroy(self.scene._p, self._p)
             self._p = C.c_void_p()
 
     def __del__(self):
@@ -377,8 +413,9 @@ def local_rows_to_global(frame: RtFrameDesc) -> np.ndarray:
     return np.array([L.rt_local_to_global_row(C.byref(frame), k) for k in range(rows)], np.int64)
 
 
-def write_ppm(path: str, fb: np.ndarray, double_scale: bool = False) -> None:
+def write_ppm(path: str, fb: np.ndarray, double_scale: bool = False, binary: bool = False) -> None:
+    """ASCII P3 as the reference prints it (main.cu:715-727, unclamped), or binary P6 (clamped to 0..255)."""
     fb = np.ascontiguousarray(fb, np.float32)
     ny, nx = fb.shape[0], fb.shape[1]
-    if host_lib().rtw_write_ppm(path.encode(), fb.ctypes.data, nx, ny, 1 if double_scale else 0) != 0:
+    if host_lib().rtw_write_ppm(path.encode(), fb.ctypes.data, nx, ny, (1 if double_scale else 0) | (2 if binary else 0)) != 0:
         raise RtError(f"cannot write {path}")

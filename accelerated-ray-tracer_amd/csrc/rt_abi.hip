@@ -148,6 +148,15 @@ struct rt_scene {
     rt_stats pending_stats;
 };
 
+// Progressive accumulation (rt_render_window): the parked pixels of one frame description between windows.
+struct rt_progressive {
+    rt_scene* scene = nullptr;
+    rt_pixel_state* d_state = nullptr;
+    size_t pixels = 0;
+    rt_frame_desc frame;         // the description it was made for (its partition must not change between windows)
+    int32_t next_sample = 0;     // the sample_begin the next window must have
+};
+
 namespace {
 
 // picks the kernel family; LDS_MODE and texture level select the instantiation inside (rt_staged_*.hip)
@@ -1120,12 +1129,59 @@ rt_status rt_debug_wave_last(rt_scene* s, unsigned long long* out, int n_waves) 
     return RT_OK;
 }
 
+static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_device, void* stream_v, int blocking, rt_stats* stats,
+                             rt_progressive* win, int32_t win_begin, int32_t win_end);
+
 rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_device, void* stream_v, int blocking, rt_stats* stats) {
+    return render_impl(s, f, fb, fb_on_device, stream_v, blocking, stats, nullptr, 0, 0);
+}
+
+rt_status rt_progressive_state_create(rt_scene* s, const rt_frame_desc* f, void** state) {
+    if (!s || !f || !state) return invalid("null argument");
+    *state = nullptr;
+    { const rt_status ud = use_device(s->device); if (ud != RT_OK) return ud; }
+    if (f->nx <= 0 || f->ny <= 0 || (long long)f->nx * f->ny >= (1ll << 31)) return invalid("bad frame size");
+    const int local_rows = rt_frame_local_rows(f);
+    if (local_rows < 0) return invalid("bad row partition");
+    rt_progressive* p = new rt_progressive;
+    p->scene = s; p->frame = *f; p->pixels = (size_t)local_rows * (size_t)f->nx; p->next_sample = 0;
+    const hipError_t e = hipMalloc((void**)&p->d_state, (p->pixels ? p->pixels : 1) * sizeof(rt_pixel_state));
+    if (e != hipSuccess) { delete p; g_last_hip_error = (int)e; g_detail = "allocating the progressive state failed"; return RT_ERR_HIP; }
+    *state = p;
+    return RT_OK;
+}
+
+rt_status rt_progressive_state_destroy(rt_scene* s, void* state) {
+    if (!state) return RT_OK;
+    rt_progressive* p = static_cast<rt_progressive*>(state);
+    if (s) (void)use_device(s->device);
+    if (p->d_state) (void)hipFree(p->d_state);
+    delete p;
+    return RT_OK;
+}
+
+rt_status rt_render_window(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_device, void* state, int32_t sample_begin, int32_t sample_end,
+                           void* stream_v, int blocking, rt_stats* stats) {
+    if (!s || !f || !fb || !state) return invalid("null argument");
+    rt_progressive* p = static_cast<rt_progressive*>(state);
+    if (p->scene != s) return invalid("rt_render_window: the state belongs to another scene");
+    if (f->nx != p->frame.nx || f->ny != p->frame.ny || f->tile_rows != p->frame.tile_rows || f->tile_first != p->frame.tile_first ||
+        f->tile_stride != p->frame.tile_stride || f->seed_base != p->frame.seed_base)
+        return invalid("rt_render_window: the frame description differs from the one the state was created for");
+    if (sample_begin != p->next_sample || sample_end <= sample_begin) return invalid("rt_render_window: windows must follow each other (sample_begin = the previous sample_end, 0 first)");
+    const rt_status st = render_impl(s, f, fb, fb_on_device, stream_v, blocking, stats, p, sample_begin, sample_end);
+    if (st == RT_OK) p->next_sample = sample_end;
+    return st;
+}
+
+static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_device, void* stream_v, int blocking, rt_stats* stats,
+                             rt_progressive* win, int32_t win_begin, int32_t win_end) {
     if (!s || !f || !fb) return invalid("null argument");
     { const rt_status ud = use_device(s->device); if (ud != RT_OK) return ud; }
     const int g_num_cu = g_devices[s->device].num_cu;
     const size_t g_lds_per_cu = g_devices[s->device].lds_per_cu;
-    if (f->nx <= 0 || f->ny <= 0 || f->ns <= 0) return invalid("nx, ny and ns must be positive");
+    const int frame_ns = win ? win_end : f->ns;       // a progressive window averages over the samples rendered so far
+    if (f->nx <= 0 || f->ny <= 0 || frame_ns <= 0) return invalid("nx, ny and ns must be positive");
     if ((long long)f->nx * f->ny >= (1ll << 31)) return invalid("frame too large");
     const int local_rows = rt_frame_local_rows(f);
     if (local_rows < 0) return invalid("bad row partition");
@@ -1135,7 +1191,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     rt_stats out;
     memset(&out, 0, sizeof(out));
     out.local_rows = local_rows;
-    out.samples = (uint64_t)local_rows * f->nx * f->ns;
+    out.samples = (uint64_t)local_rows * f->nx * (uint64_t)(win ? win_end - win_begin : f->ns);
     if (local_rows == 0) { s->pending_stats = out; if (stats) *stats = out; return RT_OK; }
 
     rt_frame_params fp;
@@ -1154,7 +1210,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     fp.ray_counter = s->d_ray_counter;
     fp.work_counter = s->d_work_counter;
     fp.seed_base = f->seed_base;
-    fp.nx = f->nx; fp.ny = f->ny; fp.ns = f->ns; fp.gamma = f->gamma;
+    fp.nx = f->nx; fp.ny = f->ny; fp.ns = frame_ns; fp.gamma = f->gamma;
     fp.background[0] = f->background[0]; fp.background[1] = f->background[1]; fp.background[2] = f->background[2];
     fp.use_gradient_bg = f->use_gradient_bg;
     fp.tile_rows = f->tile_rows; fp.tile_first = f->tile_first; fp.tile_stride = f->tile_stride;
@@ -1171,6 +1227,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
 
     // LDS residency: nodes + spheres in every workgroup of a CU if they fit that many times (2 workgroups for the lean
     // spheres-only kernels, 3 otherwise: see the workgroup shapes below), else once (one big workgroup per CU), else nodes only
+    const int kernel = win ? RT_KERNEL_STAGED : g_opt.kernel;   // (kernel 0 renders whole pixels only)
     int lds_mode = g_opt.lds_mode;
     const bool lean_family = s->spheres_only && s->tex_level < 2;
     const size_t budget1 = g_lds_per_cu - 2048;   // one workgroup per CU
@@ -1182,16 +1239,14 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         else if (s->node_bytes <= budget1) lds_mode = 1;
         else lds_mode = 0;
     }
-    if (g_opt.lds_mode < 0 && g_opt.kernel == RT_KERNEL_STAGED && g_opt.scan_nodes > 0 && s->dev.n_nodes <= g_opt.scan_nodes) lds_mode = 4;   // lockstep scan of a tiny scene
-    if (lds_mode >= 3 && g_opt.kernel != RT_KERNEL_STAGED) lds_mode = 2;
-    if (g_opt.kernel == RT_KERNEL_PIXEL) lds_mode = 0;   // the cross-check kernel reads the scene through L1/L2
+    if (g_opt.lds_mode < 0 && kernel == RT_KERNEL_STAGED && g_opt.scan_nodes > 0 && s->dev.n_nodes <= g_opt.scan_nodes) lds_mode = 4;   // lockstep scan of a tiny scene
+    if (lds_mode >= 3 && kernel != RT_KERNEL_STAGED) lds_mode = 2;
+    if (kernel == RT_KERNEL_PIXEL) lds_mode = 0;   // the cross-check kernel reads the scene through L1/L2
     size_t lds_bytes = 0;
     if (lds_mode >= 1 && lds_mode <= 3) lds_bytes += s->node_bytes;
     if (lds_mode >= 2 && lds_mode <= 3) lds_bytes += s->sphere_bytes;
     if (lds_mode == 3) lds_bytes += s->shade_bytes;
     if (lds_bytes > budget1) return invalid("requested lds_mode does not fit the CU's LDS");
-    const int kernel = g_opt.kernel;
-
     dim3 grid, block;
     int per_cu_resident = 1;   // workgroups of this launch that can be resident on one CU (persistent kernels)
     if (kernel == RT_KERNEL_PIXEL) {
@@ -1281,7 +1336,7 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
     // enqueued without a host round trip.  Scheduling only: every sample of every pixel is rendered exactly once, in
     // its pixel's stream order; frames are bit-identical with and without it (tests sweep the knobs).
     fp.tile_order = nullptr; fp.tile_cost = nullptr; fp.state_out = nullptr; fp.state_in = nullptr; fp.heavy_pixels = nullptr; fp.rank = nullptr;
-    fp.sample_begin = 0; fp.sample_end = f->ns; fp.fresh = 0;
+    fp.sample_begin = 0; fp.sample_end = frame_ns; fp.fresh = 0; fp.store_parked = 0;
     const size_t n_tiles = (size_t)fp.tiles_x * (size_t)tiles_y;
     const size_t n_pixels = (size_t)local_rows * (size_t)f->nx;
     enum { RT_HEAVY_CAP = 262144 };
@@ -1305,7 +1360,12 @@ rt_status rt_render(rt_scene* s, const rt_frame_desc* f, float* fb, int fb_on_de
         if (tiers) HIPCHK(hipStreamWaitEvent(stream, s->ev_join[pi], 0));
         return RT_OK;
     };
-    if (g_opt.lpt && kernel == RT_KERNEL_STAGED && f->ns >= 2 * g_opt.split_samples && n_tiles >= 64 && n_pixels < (1ull << 31)) {
+    if (win) {
+        // a progressive window: one launch, every pixel resumed from (first window: started in) and parked into the caller's state,
+        // and written to fb as the average so far
+        fp.state_in = win_begin > 0 ? win->d_state : nullptr; fp.state_out = win->d_state;
+        fp.sample_begin = win_begin; fp.sample_end = win_end; fp.store_parked = 1;
+    } else if (g_opt.lpt && kernel == RT_KERNEL_STAGED && f->ns >= 2 * g_opt.split_samples && n_tiles >= 64 && n_pixels < (1ull << 31)) {
         if (s->tile_capacity < n_tiles || s->pixel_capacity < n_pixels || !s->d_rank) {
             for (void* p : {(void*)s->d_tile_cost, (void*)s->d_tile_order, (void*)s->d_state, (void*)s->d_heavy_list, (void*)s->d_heavy_pixels, (void*)s->d_rank})
                 if (p) (void)hipFree(p);

@@ -136,6 +136,8 @@ struct rt_frame_params {
     int32_t sample_begin, sample_end;     // samples [sample_begin, sample_end) are rendered by this launch; ns is the frame's total
     const unsigned int* heavy_pixels;     // ranked launches: local pixel ids (lrow * nx + i) of the heavy pixels, dearest first
     const rt_rank_info* rank;             // ranked launches: tier sizes left by the ranking kernels; null = no heavy list, no tiers
+    int32_t store_parked;                 // progressive windows (rt_render_window): a pixel parked at the window's end is ALSO written to fb,
+                                          // averaged over the fp.ns samples so far
     int32_t fresh;                        // ranked FIRST part (tiers from the cost prior): state_in only carries the prior's cost and
                                           // list flag; pixels start from their seed with an empty colour sum
     int32_t tier_lds_scene;               // tier kernel: its LDS image holds spheres, materials and textures besides the leaf arrays

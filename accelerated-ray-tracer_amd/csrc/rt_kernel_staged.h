@@ -381,7 +381,8 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                             st.col[0] = col.x; st.col[1] = col.y; st.col[2] = col.z;
                             st.cost = c + (fp.state_in ? (fp.fresh ? (fp.state_in[at].cost & 0x80000000u) : fp.state_in[at].cost) : 0u);   // a middle part adds to what the pixel cost before; bit 31 ("listed") stays; a fresh part drops the prior
                             fp.state_out[at] = st;
-                            atomicAdd(&fp.tile_cost[(px_lrow >> 3) * fp.tiles_x + (px_i >> 3)], c);
+                            if (fp.tile_cost) atomicAdd(&fp.tile_cost[(px_lrow >> 3) * fp.tiles_x + (px_i >> 3)], c);
+                            if (fp.store_parked) store_pixel(fp, px_i, px_lrow, col);   // a progressive window: the frame so far
                         } else {
                             store_pixel(fp, px_i, px_lrow, col);
                         }

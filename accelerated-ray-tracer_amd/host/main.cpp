@@ -7,7 +7,7 @@
 // `--scene bouncing` is case 1, `--scene final` case 9.
 //
 //   rayTracer [--scene NAME] [--nx W --ny H] [--ns SPP] [--seed S]
-//             [--texture file.ppm] [--device N] [--gpus N] [--list]
+//             [--texture file.ppm] [--device N] [--gpus N] [--p6] [--progressive K] [--list]
 //
 // --gpus N (N > 1) spreads the frame over the first N GPUs of the node: interleaved 4-row tiles, one scene replica
 // per device, one RCCL gather to device 0 (rt_multi_*, include/rt_abi.h).  The PPM is byte-identical for every N by construction (global per-pixel seeds,
@@ -30,7 +30,8 @@ static void check(rt_status st, const char* what) {
 
 int main(int argc, char** argv) {
     std::string scene_name = "bouncing", texture_path;
-    int nx = 0, ny = 0, ns = 0, device = 0, gpus = 1;
+    int nx = 0, ny = 0, ns = 0, device = 0, gpus = 1, progressive = 0;
+    bool p6 = false;
     unsigned long long seed = 1984ull;
     for (int a = 1; a < argc; ++a) {
         std::string k = argv[a];
@@ -43,6 +44,8 @@ int main(int argc, char** argv) {
         else if (k == "--texture") texture_path = val();
         else if (k == "--device") device = atoi(val());
         else if (k == "--gpus") gpus = atoi(val());
+        else if (k == "--p6") p6 = true;                        // binary PPM (clamped); the default is the reference's ASCII P3
+        else if (k == "--progressive") progressive = atoi(val());   // render in windows of K samples (rt_render_window): same pixels, a frame after each
         else if (k == "--list") { int n = 0; const char* const* v = rtw::scene_names(&n); for (int i = 0; i < n; ++i) printf("%s\n", v[i]); return 0; }
         else { fprintf(stderr, "unknown argument %s\n", k.c_str()); return 2; }
     }
@@ -83,14 +86,31 @@ int main(int argc, char** argv) {
     } else {
         check(rt_init(device), "rt_init");
         check(rt_scene_create(&desc, &dev_scene), "rt_scene_create");
-        check(rt_render(dev_scene, &f, fb.data(), /*fb_on_device=*/0, /*stream=*/nullptr, /*blocking=*/1, &stats), "rt_render");
+        if (progressive > 0) {
+            // progressive accumulation: the per-pixel XORWOW state and colour sum are carried from window to window (the
+            // reference writes its curandState back for exactly this, main.cu:126); the last window's frame is the one-shot frame
+            void* state = nullptr;
+            check(rt_progressive_state_create(dev_scene, &f, &state), "rt_progressive_state_create");
+            rt_stats part;
+            memset(&stats, 0, sizeof(stats));
+            for (int begin = 0; begin < scene->ns; begin += progressive) {
+                const int end = begin + progressive < scene->ns ? begin + progressive : scene->ns;
+                check(rt_render_window(dev_scene, &f, fb.data(), 0, state, begin, end, nullptr, 1, &part), "rt_render_window");
+                stats.rays += part.rays; stats.ms_render += part.ms_render;
+                fprintf(stderr, "samples [%d, %d): %.3f ms\n", begin, end, part.ms_render);
+            }
+            check(rt_progressive_state_destroy(dev_scene, state), "rt_progressive_state_destroy");
+        } else {
+            check(rt_render(dev_scene, &f, fb.data(), /*fb_on_device=*/0, /*stream=*/nullptr, /*blocking=*/1, &stats), "rt_render");
+        }
     }
     fprintf(stderr, "took %g seconds.\n", stats.ms_render * 1e-3);
     fprintf(stderr, "{\"scene\": \"%s\", \"nx\": %d, \"ny\": %d, \"ns\": %d, \"gpus\": %d, \"rays\": %llu, \"ms_render\": %.3f, \"mrays_per_s\": %.1f}\n",
             scene_name.c_str(), scene->nx, scene->ny, scene->ns, gpus, (unsigned long long)stats.rays, stats.ms_render,
             stats.ms_render > 0 ? (double)stats.rays / (stats.ms_render * 1e3) : 0.0);
 
-    rtw::write_ppm_p3(stdout, fb.data(), scene->nx, scene->ny, scene->ppm_double_scale);
+    if (p6) rtw::write_ppm_p6(stdout, fb.data(), scene->nx, scene->ny, scene->ppm_double_scale);
+    else rtw::write_ppm_p3(stdout, fb.data(), scene->nx, scene->ny, scene->ppm_double_scale);
 
     if (multi) check(rt_multi_destroy(multi), "rt_multi_destroy");
     if (dev_scene) check(rt_scene_destroy(dev_scene), "rt_scene_destroy");

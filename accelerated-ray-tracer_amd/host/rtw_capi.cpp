@@ -59,10 +59,12 @@ int rtw_scene_leaf_order(void* p, int* out, int cap) {
 }
 
 // the reference's output stage: ASCII P3 to `path` ("-" = stdout)
-int rtw_write_ppm(const char* path, const float* fb, int nx, int ny, int double_scale) {
+// flags: bit 0 = the double 255.99 of bouncing_spheres (main.cu:725), bit 1 = binary P6 instead of ASCII P3
+int rtw_write_ppm(const char* path, const float* fb, int nx, int ny, int flags) {
     FILE* f = (path && std::string(path) != "-") ? fopen(path, "wb") : stdout;
     if (!f) return -1;
-    rtw::write_ppm_p3(f, fb, nx, ny, double_scale != 0);
+    if (flags & 2) rtw::write_ppm_p6(f, fb, nx, ny, (flags & 1) != 0);
+    else rtw::write_ppm_p3(f, fb, nx, ny, (flags & 1) != 0);
     if (f != stdout) fclose(f); else fflush(f);
     return 0;
 }

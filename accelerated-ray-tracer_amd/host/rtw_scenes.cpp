@@ -415,4 +415,19 @@ void write_ppm_p3(FILE* f, const float* fb, int nx, int ny, bool double_scale) {
     fwrite(buf.data(), 1, buf.size(), f);
 }
 
+// Binary PPM (optional): the same quantisation, int(255.99 * c), one byte per channel -- so values the P3 form
+// prints above 255 (emitters: the reference does not clamp, main.cu:715-727) are clamped to 255 here, and negatives to 0.
+void write_ppm_p6(FILE* f, const float* fb, int nx, int ny, bool double_scale) {
+    fprintf(f, "P6\n%d %d\n255\n", nx, ny);
+    std::vector<unsigned char> row((size_t)nx * 3);
+    for (int j = ny - 1; j >= 0; --j) {
+        for (int i = 0; i < nx * 3; ++i) {
+            const float c = fb[(size_t)j * nx * 3 + i];
+            const int v = double_scale ? int(255.99 * c) : int(255.99f * c);
+            row[(size_t)i] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+        fwrite(row.data(), 1, row.size(), f);
+    }
+}
+
 }  // namespace rtw

@@ -42,5 +42,6 @@ bool load_ppm(const std::string& path, std::vector<unsigned char>& rgb, int& w, 
 
 // The reference's output stage (main.cu:715-727): ASCII P3, rows ny-1..0, int(255.99*c), no clamp.
 void write_ppm_p3(FILE* f, const float* fb, int nx, int ny, bool double_scale);
+void write_ppm_p6(FILE* f, const float* fb, int nx, int ny, bool double_scale);   // binary, clamped to 0..255
 
 }  // namespace rtw

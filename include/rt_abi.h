@@ -229,6 +229,20 @@ rt_status rt_render(rt_scene* scene, const rt_frame_desc* f, float* fb, int fb_o
                     void* stream, int blocking, rt_stats* stats);
 rt_status rt_frame_finish(rt_scene* scene, rt_stats* stats);
 
+/* ---- progressive accumulation (the reference writes every pixel's curandState back at the end of render(),
+ * main.cu:126, which is what would allow it and what nothing in the reference uses) ----
+ * rt_render_window renders samples [sample_begin, sample_end) of every pixel the frame description assigns to the call,
+ * continuing from `state` -- device memory made by rt_progressive_state_create for that frame description, opaque to the
+ * caller: per pixel the XORWOW state, the colour sum and the rays so far -- and writes to fb the frame averaged over the
+ * sample_end samples rendered so far, gamma applied (f->ns is ignored).  sample_begin must be 0 on the first call for a
+ * state and the previous call's sample_end afterwards; anything else is RT_ERR_INVALID.  A sequence of windows gives
+ * pixels bit-identical to one rt_render with ns = the last sample_end (tests/test_gpu_parity.py); stats->rays counts the
+ * window's rays.  Windows run as one launch each (no cost-aware split: a window is usually short). */
+rt_status rt_progressive_state_create(rt_scene* scene, const rt_frame_desc* f, void** state);
+rt_status rt_progressive_state_destroy(rt_scene* scene, void* state);
+rt_status rt_render_window(rt_scene* scene, const rt_frame_desc* f, float* fb, int fb_on_device, void* state,
+                           int32_t sample_begin, int32_t sample_end, void* stream, int blocking, rt_stats* stats);
+
 /* ---- several GPUs of one node from one host thread ----
  * The reference is single-GPU (one render<<<>>> launch, main.cu:707); these entry points are what its host function
  * would call to spread that launch over the N GPUs of a node: rt_init_devices(N) replaces rt_init, rt_multi_create /

@@ -353,3 +353,32 @@ def test_split_frame_schedule_matches_oracle(gpu, orc, name, nx, ny, ns):
         fb, st = render(gpu, hs, 3, opts, ns=ns)
         assert st.rays == cnt["rays"], (opts, st.rays, cnt["rays"])
         assert_frames_equal(fb, ref, f"{name} {opts}")
+
+
+@pytest.mark.parametrize("name,nx,ny", [("bouncing", 96, 64), ("cornell_smoke", 64, 64), ("final", 48, 48)])
+def test_progressive_windows_equal_one_shot(gpu, orc, name, nx, ny):
+    """rt_render_window (progressive accumulation on the carried per-pixel RNG state, main.cu:126): windows
+    [0, 5), [5, 12), [12, 24) leave after each window the frame a one-shot render of that many samples gives, bit for bit --
+    and the last one equals the oracle; ray counts add up; a window out of sequence is refused."""
+    img, iw, ih = gpu.default_texture(name)
+    hs = gpu.HostScene(name, nx, ny, img, iw, ih)
+    gpu.reset_options()
+    ds = gpu.DeviceScene(hs)
+    try:
+        ref, cnt = orc.OracleScene(name, nx, ny, img, iw, ih).render(24)
+        prog = ds.progressive(hs.frame(ns=24))
+        rays = 0
+        for begin, end in ((0, 5), (5, 12), (12, 24)):
+            fb, st = prog.render(begin, end)
+            rays += st.rays
+            one, _ = ds.render(hs.frame(ns=end))
+            assert np.array_equal(fb.view(np.uint32), one.view(np.uint32)), (name, begin, end)
+        assert rays == cnt["rays"]
+        assert_frames_equal(fb, ref, f"{name} progressive")
+        with pytest.raises(gpu.RtError):
+            prog.render(30, 40)
+        with pytest.raises(gpu.RtError):
+            prog.render(24, 24)
+        prog.close()
+    finally:
+        ds.close()

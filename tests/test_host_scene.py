@@ -125,6 +125,22 @@ def test_ppm_output_format(art, tmp_path):
     data, w, h = art.load_ppm(str(p)) if False else (None, 0, 0)   # loader takes maxval-255 files of bytes only
 
 
+def test_binary_ppm_output(art, tmp_path):
+    """The optional binary form: P6, the same quantisation and row order as the P3 form, one byte per
+    channel -- what P3 prints above 255 (the reference does not clamp) is clamped; the texture loader reads it back."""
+    fb = np.zeros((2, 3, 3), np.float32)
+    fb[0, 0] = [0.0, 0.5, 1.0]
+    fb[1, 2] = [2.0, 0.25, -0.5]
+    p = tmp_path / "o6.ppm"
+    art.write_ppm(str(p), fb, binary=True)
+    raw = p.read_bytes()
+    assert raw.startswith(b"P6\n3 2\n255\n") and len(raw) == len(b"P6\n3 2\n255\n") + 18
+    data, w, h = art.load_ppm(str(p))
+    px = data.reshape(2, 3, 3)
+    assert (w, h) == (3, 2)
+    assert px[1, 0].tolist() == [0, 127, 255] and px[0, 2].tolist() == [255, 63, 0]
+
+
 def test_ppm_texture_loader(art, tmp_path):
     rgb = (np.arange(4 * 3 * 3) % 251).astype(np.uint8)
     p = tmp_path / "t.ppm"
