@@ -70,6 +70,9 @@ struct rt_options {
     int tier_priority = 1;       // s_setprio level of the tier kernel's waves (1 instead of 3: 80.6 -> 76.3 ms on a half, 70.2 -> 62.7 on a quarter of
                                  // the headline frame, nothing on the whole frame or an eighth: profiles/r03_share_sweep_pass2.log)
     int semi_priority = 1;       // s_setprio level of the semi workgroups' waves (tier 3 on workgroups of its own)
+    int handoff = 1;             // tail hand-off (rt_device.h): the main kernel's last pixels are finished by a launch of the tier kernel after it
+    int handoff_poll = 6;        // ... looked for every 2^this-th time a wave runs its new-path stage
+    int handoff_pixels = -1;     // ... when at most this many are in flight and the tile queue is dry; -1 = auto (render_impl)
     int sparse_eager = 0;
     int sparse_work_percent = 5;  // tiers 0-2 hold at most this share of the frame's work (rays so far); dearer-than-average pixels beyond it go to tier 3
     int sparse_wg_percent = 35;   // at most this share of the workgroups starts in sparse mode
@@ -136,6 +139,8 @@ struct rt_scene {
     unsigned long long* d_heavy_list = nullptr;   // (cost << 32 | pixel), unsorted, from rt_collect_heavy_kernel
     unsigned int* d_heavy_pixels = nullptr;       // heavy pixels, dearest first
     size_t tile_capacity = 0, pixel_capacity = 0;
+    unsigned long long* d_handoff = nullptr;      // tail hand-off queue: (sample << 32 | pixel), one entry per resident lane at most
+    size_t handoff_capacity = 0;
     rt_rank_info* d_rank = nullptr;               // tier sizes of the next ranked launch (written and read on the device only)
     unsigned int* d_cal_cost = nullptr;           // cost prior: rays per pixel of the calibration frame (cal_nx x cal_ny at 4 spp)
     int cal_nx = 0, cal_ny = 0;
@@ -609,6 +614,9 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "heavy_factor_x10") { if (value < 10 || value > 1000) return invalid("heavy_factor_x10: 10..1000"); g_opt.heavy_factor_x10 = value; }
     else if (k == "tier_auto") { if (value < 0 || value > 1) return invalid("tier_auto: 0 or 1"); g_opt.tier_auto = value; }
     else if (k == "tier_kernel") { if (value < 0 || value > 1) return invalid("tier_kernel: 0 or 1"); g_opt.tier_kernel = value; }
+    else if (k == "handoff") { if (value < 0 || value > 1) return invalid("handoff: 0 or 1"); g_opt.handoff = value; }
+    else if (k == "handoff_poll") { if (value < 0 || value > 16) return invalid("handoff_poll: 0..16"); g_opt.handoff_poll = value; }
+    else if (k == "handoff_pixels") { if (value < -1 || value > (1 << 24)) return invalid("handoff_pixels: -1 (auto) or 0..16777216"); g_opt.handoff_pixels = value; }
     else if (k == "prior") { if (value < 0 || value > 1) return invalid("prior: 0 or 1"); g_opt.prior = value; }
     else if (k == "presplit_samples") { if (value < 0 || value > 4096) return invalid("presplit_samples: 0..4096"); g_opt.presplit_samples = value; }
     else if (k == "resplit_samples") { if (value < 0 || value > 65536) return invalid("resplit_samples: 0..65536"); g_opt.resplit_samples = value; }
@@ -651,6 +659,7 @@ rt_status rt_scene_destroy(rt_scene* s) {
     if (s->d_heavy_list) (void)hipFree(s->d_heavy_list);
     if (s->d_heavy_pixels) (void)hipFree(s->d_heavy_pixels);
     if (s->d_rank) (void)hipFree(s->d_rank);
+    if (s->d_handoff) (void)hipFree(s->d_handoff);
     if (s->d_cal_cost) (void)hipFree(s->d_cal_cost);
     if (s->tier_stream) (void)hipStreamDestroy(s->tier_stream);
     for (int k = 0; k < 4; ++k) { if (s->ev_fork[k]) (void)hipEventDestroy(s->ev_fork[k]); if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]); }
@@ -986,7 +995,7 @@ rt_status rt_internal_scene_create_on(int device, const rt_scene_desc* d, rt_sce
     s->node_bytes = (size_t)d->n_nodes * sizeof(rt_node);
     s->sphere_bytes = (size_t)d->n_spheres * sizeof(rt_sphere);
     hipError_t e;
-    if ((e = hipMalloc((void**)&s->d_ray_counter, RT_COUNTER_BYTES)) != hipSuccess || (e = hipMalloc((void**)&s->d_work_counter, 64)) != hipSuccess ||
+    if ((e = hipMalloc((void**)&s->d_ray_counter, RT_COUNTER_BYTES)) != hipSuccess || (e = hipMalloc((void**)&s->d_work_counter, RT_WORK_COUNTER_BYTES)) != hipSuccess ||
         (e = hipEventCreate(&s->ev_start)) != hipSuccess || (e = hipEventCreate(&s->ev_stop)) != hipSuccess) {
         g_last_hip_error = (int)e; g_detail = "allocating per-frame resources failed";
         rt_scene_destroy(s);
@@ -1093,6 +1102,15 @@ rt_status rt_frame_finish(rt_scene* s, rt_stats* stats) {
     }
     s->frame_pending = false;
     if (stats) *stats = s->pending_stats;
+    return RT_OK;
+}
+
+// Tail hand-off of the last frame (diagnostics, every build): [0] pixels the main kernel handed to the tail launches, summed over
+// the frame's parts, [1] the samples those pixels still had to go.
+rt_status rt_debug_handoff(rt_scene* s, unsigned long long* out2) {
+    if (!s || !out2) return invalid("null argument");
+    { const rt_status ud = use_device(s->device); if (ud != RT_OK) return ud; }
+    HIPCHK(hipMemcpy(out2, s->d_ray_counter + 28, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -1316,6 +1334,15 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
             if (tier_grid < 1u) tier_grid = 1u;
         }
     }
+    // the tail launch has the machine to itself: as many tier workgroups per CU as registers (launch bounds: 4 resp. 3 waves per SIMD,
+    // a workgroup is one wave per SIMD) and LDS hold
+    unsigned tail_grid = 0;
+    if (tier_possible && g_opt.handoff) {
+        const unsigned by_lds = (unsigned)(g_lds_per_cu / (tier_lds + 512));
+        const unsigned by_regs = lean_family ? 4u : 3u;
+        tail_grid = (unsigned)g_num_cu * (by_lds < by_regs ? by_lds : by_regs);
+        if (tail_grid < 1u) tail_grid = 1u;
+    }
     out.kernel_variant = kernel * 1000 + lds_mode * 100 + s->tex_level * 10 + (s->spheres_only ? 1 : 0);
     out.workgroups = (int)grid.x; out.threads_per_group = (int)block.x; out.lds_bytes = (int)lds_bytes;
 
@@ -1346,7 +1373,7 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
     // one part of the frame: the tier kernel (ranked parts of scenes that have tier data) on its own stream, forked from
     // and joined to the caller's stream by events, and the main kernel
     auto launch_part = [&](const rt_frame_params& q, dim3 grid_q, bool ranked) -> rt_status {
-        HIPCHK(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
+        HIPCHK(hipMemsetAsync(s->d_work_counter, 0, RT_WORK_COUNTER_BYTES, stream));
         const bool tiers = ranked && tier_possible;
         const int pi = part_index++ & 3;
         if (tiers) {
@@ -1358,6 +1385,13 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
         }
         HIPCHK(launch_render(kernel, lds_mode, s, q, grid_q, block, lds_bytes, stream));
         if (tiers) HIPCHK(hipStreamWaitEvent(stream, s->ev_join[pi], 0));
+        if (q.handoff_queue) {
+            // the tail: the pixels the main kernel handed off, one per wave, on the whole machine (stream order: after both kernels)
+            rt_frame_params t = q;
+            t.tail_mode = 1;
+            HIPCHK(s->spheres_only ? rt_launch_tier_spheres(s->tex_level, s->dev, t, dim3(tail_grid), tier_lds, stream)
+                                   : rt_launch_tier_general(s->tex_level, s->need_uv, s->dev, t, dim3(tail_grid), tier_lds, stream));
+        }
         return RT_OK;
     };
     if (win) {
@@ -1378,6 +1412,23 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
             HIPCHK(hipMalloc((void**)&s->d_heavy_pixels, (size_t)RT_HEAVY_CAP * sizeof(unsigned int)));
             HIPCHK(hipMalloc((void**)&s->d_rank, sizeof(rt_rank_info)));
             s->tile_capacity = n_tiles; s->pixel_capacity = n_pixels;
+        }
+        if (tail_grid > 0) {
+            // tail hand-off (rt_device.h): a lane hands off at most one pixel per launch, so the queue holds one entry per resident lane
+            const size_t lanes = (size_t)g_num_cu * (size_t)per_cu_resident * (size_t)block.x;
+            if (s->handoff_capacity < lanes) {
+                if (s->d_handoff) (void)hipFree(s->d_handoff);
+                s->d_handoff = nullptr; s->handoff_capacity = 0;
+                HIPCHK(hipMalloc((void**)&s->d_handoff, lanes * sizeof(unsigned long long)));
+                s->handoff_capacity = lanes;
+            }
+            fp.handoff_queue = s->d_handoff; fp.handoff_state = s->d_state;
+            fp.handoff_poll_mask = (1 << g_opt.handoff_poll) - 1;
+            // auto: six pixels per wave of the tail launch (the headline frame: 18432 of 960000; 8192 .. 32768 measure the same,
+            // profiles/r03_handoff.log), and never more than 1/32 of the pixels (small frames and shares)
+            const size_t tail_waves = (size_t)tail_grid * (RT_TIER_THREADS / 64);
+            const size_t cap_px = n_pixels / 32;
+            fp.handoff_pixels = g_opt.handoff_pixels >= 0 ? g_opt.handoff_pixels : (int32_t)(6 * tail_waves < cap_px ? 6 * tail_waves : cap_px);
         }
         // One ranking: three small kernels order the tiles, list the heavy pixels and size the tiers for the launch
         // described by `q` (which resumes every pixel from d_state).  The grids are fixed here, before the sizes are known:

@@ -120,6 +120,10 @@ struct rt_scene_dev {
     rt_camera camera;
 };
 
+enum { RT_WC_DEAD = 64,        // work_counter[]: lanes of the main launch that have run out of work
+       RT_WC_PUSHED = 65,      // entries pushed to handoff_queue
+       RT_WC_TAIL_HEAD = 66,   // the tail launch's queue head
+       RT_WORK_COUNTER_BYTES = 512 };
 struct rt_frame_params {
     float* fb;                            // compact local rows, nx*3 floats each
     unsigned long long* ray_counter;      // += rays traced
@@ -141,6 +145,16 @@ struct rt_frame_params {
     int32_t fresh;                        // ranked FIRST part (tiers from the cost prior): state_in only carries the prior's cost and
                                           // list flag; pixels start from their seed with an empty colour sum
     int32_t tier_lds_scene;               // tier kernel: its LDS image holds spheres, materials and textures besides the leaf arrays
+    // Tail hand-off (rt_abi.hip, "tail"): once the tile queue is dry and at most handoff_pixels pixels are still in flight on the
+    // main kernel's lanes (= lanes that still have work), every lane parks its pixel at its next sample boundary into handoff_state[pixel] and pushes
+    // (sample << 32 | pixel) to handoff_queue; the tier kernel, launched again AFTER the main kernel (tail_mode), finishes
+    // them one pixel per wave.  Its counters live in a cache line of their own, away from the queue heads at work_counter[0..4]: with
+    // the polled word in the queue heads' line every pixel fetch of the frame slowed down (headline 96 -> 118 ms).
+    unsigned long long* handoff_queue;    // null = no hand-off
+    rt_pixel_state* handoff_state;
+    int32_t handoff_pixels;
+    int32_t handoff_poll_mask;
+    int32_t tail_mode;                    // tier kernel: serve handoff_queue instead of tier 1 of the heavy list
     uint64_t seed_base;
     int32_t nx, ny, ns;
     float gamma;

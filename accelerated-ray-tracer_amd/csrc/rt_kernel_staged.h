@@ -89,6 +89,10 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     float cur_a = 1.f;           // dot(d, d) of the current ray (sphere.cuh:58), hoisted out of the sphere tests
     bool have_pixel = false, first = true, finite_inv = true;
     bool tier3_open = true;      // this lane has not yet seen the end of the tier-3 queue
+    bool leave = false;          // tail hand-off (rt_device.h): the frame's last pixels leave for the tail launch at their next sample boundary.  Wave-uniform
+    unsigned int poll_tick = 0, wave_dead = 0;   // ... lanes of this wave counted in work_counter[5]
+    bool dry_seen = false;       // a lane of this wave has found its queue empty: from then on the wave looks at the count now and then
+    const uint32_t total_lanes = (uint32_t)((int)gridDim.x - rk.main_skip_wgs) * blockDim.x;
     unsigned int rays = 0, rays_at_pixel_start = 0;
     // Sparse mode (see rt_abi.hip, "heavy tiles"): the first sparse_wgs workgroups start by serving tier 2 of the list with
     // only every sparse_stride-th lane, because a lane's rays advance ~2x faster in a wave with few live lanes and those
@@ -366,12 +370,22 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
             if (n_new > 0 && (n_new >= newpath_need || force || eager)) {
                 ran_stage = true;
                 DIAG_ADD(9, 1); DIAG_ADD(10, n_new);
+                // tail hand-off: once one of its lanes has found its queue empty, a wave looks every 2^k-th time round at how many
+                // lanes of the launch still have work.  The look is a load that misses every cache and stalls the wave: every 8th
+                // time round costs the headline frame 2 ms more than every 64th (profiles/r03_handoff.log).
+                if (fp.handoff_queue && !leave && dry_seen && (++poll_tick & (unsigned)fp.handoff_poll_mask) == 0u) {
+                    const uint32_t dead = __hip_atomic_load(fp.work_counter + RT_WC_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    leave = __builtin_amdgcn_readfirstlane((int)(total_lanes - dead)) <= fp.handoff_pixels;
+                }
+                bool ran_dry = false;      // this lane found its queue empty
                 if (node == ST_NEWPATH) {
                     if (!first) { col = col + radiance; ++sample; }
                     first = false;
                     bool alive = true;
-                    if (have_pixel && sample >= fp.sample_end) {
-                        if (fp.state_out) {
+                    const bool part_done = sample >= fp.sample_end;
+                    if (have_pixel && (part_done || leave)) {
+                        const bool hand = !part_done;      // samples [sample, sample_end) go to the tail launch
+                        if (fp.state_out || hand) {
                             // first part of a split frame: park the pixel at this sample boundary (no path is in flight
                             // here, so the XORWOW state and the colour sum are the whole state) and record what it cost
                             const unsigned int c = rays - rays_at_pixel_start;
@@ -380,9 +394,13 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                             st.rng[0] = g.v0; st.rng[1] = g.v1; st.rng[2] = g.v2; st.rng[3] = g.v3; st.rng[4] = g.v4; st.rng[5] = g.d;
                             st.col[0] = col.x; st.col[1] = col.y; st.col[2] = col.z;
                             st.cost = c + (fp.state_in ? (fp.fresh ? (fp.state_in[at].cost & 0x80000000u) : fp.state_in[at].cost) : 0u);   // a middle part adds to what the pixel cost before; bit 31 ("listed") stays; a fresh part drops the prior
-                            fp.state_out[at] = st;
+                            (hand ? fp.handoff_state : fp.state_out)[at] = st;
                             if (fp.tile_cost) atomicAdd(&fp.tile_cost[(px_lrow >> 3) * fp.tiles_x + (px_i >> 3)], c);
-                            if (fp.store_parked) store_pixel(fp, px_i, px_lrow, col);   // a progressive window: the frame so far
+                            if (hand) {
+                                const uint32_t slot = atomicAdd(fp.work_counter + RT_WC_PUSHED, 1u);
+                                fp.handoff_queue[slot] = ((unsigned long long)(uint32_t)sample << 32) | (unsigned long long)at;
+                                alive = false;
+                            } else if (fp.store_parked) store_pixel(fp, px_i, px_lrow, col);   // a progressive window: the frame so far
                         } else {
                             store_pixel(fp, px_i, px_lrow, col);
                         }
@@ -394,7 +412,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                             // tier 2 of the heavy list (sorted by descending cost; its first tier1_items entries are the tier kernel's)
                             if (((threadIdx.x & 63) % (unsigned)rk.sparse_stride) != 0u) { alive = false; break; }
                             const uint32_t k2 = atomicAdd(fp.work_counter + 1, 1u);
-                            if (k2 >= rk.tier2_items) { alive = false; break; }
+                            if (k2 >= rk.tier2_items) { alive = false; ran_dry = true; break; }
                             const uint32_t at = rk.tier1_items + k2;
                             const uint32_t pix = fp.heavy_pixels[at];
                             px_lrow = (int)(pix / (uint32_t)fp.nx); px_i = (int)(pix - (uint32_t)px_lrow * (uint32_t)fp.nx);
@@ -405,13 +423,13 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                             if (semi && ((threadIdx.x & 63) % (unsigned)rk.semi_stride) != 0u) { alive = false; break; }
                             const uint32_t k3 = atomicAdd(fp.work_counter + 4, 1u);
                             const uint32_t first3 = rk.tier1_items + rk.tier2_items;
-                            if (first3 + k3 >= rk.heavy_items) { tier3_open = false; if (semi) { alive = false; break; } continue; }
+                            if (first3 + k3 >= rk.heavy_items) { tier3_open = false; if (semi) { alive = false; ran_dry = true; break; } continue; }
                             const uint32_t pix = fp.heavy_pixels[first3 + k3];
                             px_lrow = (int)(pix / (uint32_t)fp.nx); px_i = (int)(pix - (uint32_t)px_lrow * (uint32_t)fp.nx);
                             ok = true;
                         } else {
                             const uint32_t w = atomicAdd(fp.work_counter, 1u);
-                            if (w >= fp.work_items) { alive = false; break; }
+                            if (w >= fp.work_items) { alive = false; ran_dry = true; break; }
                             ok = work_to_pixel(fp, w, px_i, px_lrow);
                             // pixels in the heavy list belong to the tiers
                             if (ok && rk.heavy_items && (fp.state_in[(size_t)px_lrow * fp.nx + px_i].cost & 0x80000000u) != 0u) ok = false;
@@ -447,6 +465,14 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
 #endif
                     }
                 }
+                if (fp.handoff_queue) {   // lanes of this launch that have run out of work: work_counter[RT_WC_DEAD]
+                    dry_seen = dry_seen || __ballot(ran_dry) != 0ull;
+                    const unsigned int n_died = (unsigned int)__popcll(__ballot(node == ST_DEAD));
+                    if (n_died != wave_dead) {
+                        if ((threadIdx.x & 63) == 0) atomicAdd(fp.work_counter + RT_WC_DEAD, n_died - wave_dead);   // (no return value: nothing waits for it)
+                        wave_dead = n_died;
+                    }
+                }
             }
         }
         DIAG_T(4);
@@ -465,6 +491,10 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
             // nothing walking, nothing waiting: every lane is ST_DEAD
             if (!sparse && !semi) break;
             sparse = false; semi = false;           // our queue is drained and our pixels are done: become an ordinary wave
+            if (fp.handoff_queue && wave_dead) {    // its lanes are alive again
+                if ((threadIdx.x & 63) == 0) atomicAdd(fp.work_counter + RT_WC_DEAD, 0u - wave_dead);
+                wave_dead = 0;
+            }
             __builtin_amdgcn_s_setprio(0);
             node = ST_NEWPATH; first = true; have_pixel = false;
         }

@@ -219,9 +219,11 @@ DEV bool trace_wave(const TierView& tv, const SceneView& sc, const Ray& r, HitIn
 template <bool SPHERES_ONLY, int TEX, bool NEED_UV, bool LDS_SCENE>
 __global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4 : 3) rt_tier_kernel(rt_scene_dev sd, rt_frame_params fp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // tail_mode: the launch after the main kernel that finishes the pixels it handed off (rt_device.h, "tail hand-off")
+    const bool tail = (fp.tail_mode & 1) != 0;
     const rt_rank_info* q = fp.rank;
-    const int my_wgs = q->tier1_wgs;
-    const uint32_t n_items = q->tier1_items;
+    const uint32_t n_items = tail ? fp.work_counter[RT_WC_PUSHED] : q->tier1_items;
+    const int my_wgs = tail ? (int)((n_items + RT_TIER_THREADS / 64 - 1) / (RT_TIER_THREADS / 64)) : q->tier1_wgs;
     if ((int)blockIdx.x >= my_wgs) return;        // the grid is fixed before the ranking has sized the tier
     // these waves are the frame's critical path: they win instruction-issue arbitration on their SIMD (option tier_priority)
     if (fp.tier_priority >= 3) __builtin_amdgcn_s_setprio(3);
@@ -269,18 +271,23 @@ __global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4
 #endif
     for (;;) {
         uint32_t idx = 0;
-        if ((threadIdx.x & 63) == 0) idx = atomicAdd(fp.work_counter + 2, 1u);
+        if ((threadIdx.x & 63) == 0) idx = atomicAdd(fp.work_counter + (tail ? RT_WC_TAIL_HEAD : 2), 1u);
         idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
         if (idx >= n_items) break;
-        const uint32_t pix = fp.heavy_pixels[idx];
+        const unsigned long long item = tail ? fp.handoff_queue[idx] : (unsigned long long)fp.heavy_pixels[idx];
+        const uint32_t pix = (uint32_t)item;
+        const int first_sample = tail ? (int)(item >> 32) : fp.sample_begin;
+        if (tail && (threadIdx.x & 63) == 0) {     // rt_debug_handoff
+            atomicAdd(fp.ray_counter + 28, 1ull); atomicAdd(fp.ray_counter + 29, (unsigned long long)(fp.sample_end - first_sample));
+        }
         const int lrow = (int)(pix / (uint32_t)fp.nx), i = (int)(pix - (uint32_t)lrow * (uint32_t)fp.nx);
         const int j = local_to_global_row(fp, lrow);
         rt_xorwow pg;
         f3 pcol;
         uint32_t cost_before;
         {
-            const rt_pixel_state st = fp.state_in[pix];
-            if (fp.fresh) {                        // first part: the state only carries the cost prior and the list flag
+            const rt_pixel_state st = tail ? fp.handoff_state[pix] : fp.state_in[pix];
+            if (fp.fresh && !tail) {               // first part: the state only carries the cost prior and the list flag
                 rt_xorwow_seed(pg, fp.seed_base + (uint64_t)(j * fp.nx + i));   // render_init, main.cu:101-104
                 pcol = mk3(0, 0, 0);
                 cost_before = st.cost & 0x80000000u;
@@ -291,7 +298,7 @@ __global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4
             }
         }
         unsigned int pixel_rays = 0;
-        for (int sidx = fp.sample_begin; sidx < fp.sample_end; ++sidx) {                 // main.cu:119-125
+        for (int sidx = first_sample; sidx < fp.sample_end; ++sidx) {                    // main.cu:119-125
             const float u = ((float)i + rt_xorwow_uniform(pg)) / (float)fp.nx;
             const float v = ((float)j + rt_xorwow_uniform(pg)) / (float)fp.ny;
             Ray r = camera_get_ray(sd.camera, u, v, pg);
@@ -329,7 +336,7 @@ __global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4
                 so.col[0] = pcol.x; so.col[1] = pcol.y; so.col[2] = pcol.z;
                 so.cost = cost_before + pixel_rays;   // (bit 31, "listed", stays: this launch's tile queue must keep skipping the pixel)
                 fp.state_out[pix] = so;
-                atomicAdd(&fp.tile_cost[(lrow >> 3) * fp.tiles_x + (i >> 3)], pixel_rays);
+                if (fp.tile_cost) atomicAdd(&fp.tile_cost[(lrow >> 3) * fp.tiles_x + (i >> 3)], pixel_rays);
             } else {
                 store_pixel(fp, i, lrow, pcol);
             }
