@@ -71,7 +71,7 @@ struct rt_options {
                                  // the headline frame, nothing on the whole frame or an eighth: profiles/r03_share_sweep_pass2.log)
     int semi_priority = 1;       // s_setprio level of the semi workgroups' waves (tier 3 on workgroups of its own)
     int handoff = 1;             // tail hand-off (rt_device.h): the main kernel's last pixels are finished by a launch of the tier kernel after it
-    int handoff_poll = 6;        // ... looked for every 2^this-th time a wave runs its new-path stage
+    int handoff_poll_us = 1000;  // ... looked for this often by each wave that has run out of queued work
     int handoff_pixels = -1;     // ... when at most this many are in flight and the tile queue is dry; -1 = auto (render_impl)
     int sparse_eager = 0;
     int sparse_work_percent = 5;  // tiers 0-2 hold at most this share of the frame's work (rays so far); dearer-than-average pixels beyond it go to tier 3
@@ -615,7 +615,7 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "tier_auto") { if (value < 0 || value > 1) return invalid("tier_auto: 0 or 1"); g_opt.tier_auto = value; }
     else if (k == "tier_kernel") { if (value < 0 || value > 1) return invalid("tier_kernel: 0 or 1"); g_opt.tier_kernel = value; }
     else if (k == "handoff") { if (value < 0 || value > 1) return invalid("handoff: 0 or 1"); g_opt.handoff = value; }
-    else if (k == "handoff_poll") { if (value < 0 || value > 16) return invalid("handoff_poll: 0..16"); g_opt.handoff_poll = value; }
+    else if (k == "handoff_poll_us") { if (value < 1 || value > 1000000) return invalid("handoff_poll_us: 1..1000000"); g_opt.handoff_poll_us = value; }
     else if (k == "handoff_pixels") { if (value < -1 || value > (1 << 24)) return invalid("handoff_pixels: -1 (auto) or 0..16777216"); g_opt.handoff_pixels = value; }
     else if (k == "prior") { if (value < 0 || value > 1) return invalid("prior: 0 or 1"); g_opt.prior = value; }
     else if (k == "presplit_samples") { if (value < 0 || value > 4096) return invalid("presplit_samples: 0..4096"); g_opt.presplit_samples = value; }
@@ -1384,14 +1384,15 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
             HIPCHK(hipEventRecord(s->ev_join[pi], s->tier_stream));
         }
         HIPCHK(launch_render(kernel, lds_mode, s, q, grid_q, block, lds_bytes, stream));
-        if (tiers) HIPCHK(hipStreamWaitEvent(stream, s->ev_join[pi], 0));
         if (q.handoff_queue) {
-            // the tail: the pixels the main kernel handed off, one per wave, on the whole machine (stream order: after both kernels)
+            // the tail: the pixels the main kernel handed off, one per wave, on whatever the tier kernel -- which may still be
+            // running on its own stream: other pixels, other queue head -- leaves free of the machine
             rt_frame_params t = q;
             t.tail_mode = 1;
             HIPCHK(s->spheres_only ? rt_launch_tier_spheres(s->tex_level, s->dev, t, dim3(tail_grid), tier_lds, stream)
                                    : rt_launch_tier_general(s->tex_level, s->need_uv, s->dev, t, dim3(tail_grid), tier_lds, stream));
         }
+        if (tiers) HIPCHK(hipStreamWaitEvent(stream, s->ev_join[pi], 0));
         return RT_OK;
     };
     if (win) {
@@ -1423,7 +1424,7 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
                 s->handoff_capacity = lanes;
             }
             fp.handoff_queue = s->d_handoff; fp.handoff_state = s->d_state;
-            fp.handoff_poll_mask = (1 << g_opt.handoff_poll) - 1;
+            fp.handoff_poll_ticks = g_opt.handoff_poll_us * 100;
             // auto: six pixels per wave of the tail launch (the headline frame: 18432 of 960000; 8192 .. 32768 measure the same,
             // profiles/r03_handoff.log), and never more than 1/32 of the pixels (small frames and shares)
             const size_t tail_waves = (size_t)tail_grid * (RT_TIER_THREADS / 64);
@@ -1454,10 +1455,11 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
                 }
                 // shares, lean family: re-fitted in round 3 with the tier kernel beside the main kernel (tools/share_sweep.py on rank 0
                 // of the 1200x800 and 1920x1080 frames, profiles/r03_share_sweep_pass*.log; slowest-rank tables in DESIGN.md section 6)
+                // -- and again with the tail hand-off, which takes over what the largest tiers were there for (rank 0 of 8: 48.1 ms with
+                // round 3's first fit 16384 / 1.5x, 40.6 ms with the quarter's sizes; rank 0 of 2: 66.2 -> 62.6 ms, profiles/r03_handoff_shares.log)
                 else if (lean_family) {
-                    if (per_lane > 1.375) { e_tier1_pixels = 4096; e_tier1_factor = 30; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 25; e_sparse_percent = 80; }
-                    else if (per_lane > 0.6875) { e_tier1_pixels = 8192; e_tier1_factor = 20; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 20; e_sparse_percent = 80; e_work_percent = 40; }
-                    else { e_tier1_pixels = 16384; e_tier1_factor = 15; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 15; e_sparse_percent = 80; e_work_percent = 60; }
+                    if (per_lane > 1.375) { e_tier1_pixels = 1536; e_tier1_factor = 40; e_tier1_depth = 3; e_heavy_factor = 20; e_sparse_factor = 40; e_sparse_percent = 80; e_work_percent = 5; }
+                    else { e_tier1_pixels = 8192; e_tier1_factor = 20; e_tier1_depth = 4; e_heavy_factor = 15; e_sparse_factor = 20; e_sparse_percent = 80; e_work_percent = 40; }
                 }
                 // shares, other families: round 2's sizes (Book-2 final's 1/8 share: 216 ms with these, 236 with the lean family's,
                 // 252 without a tier kernel, profiles/r03_share_sweep_final_eighth.log)

@@ -153,7 +153,7 @@ struct rt_frame_params {
     unsigned long long* handoff_queue;    // null = no hand-off
     rt_pixel_state* handoff_state;
     int32_t handoff_pixels;
-    int32_t handoff_poll_mask;
+    int32_t handoff_poll_ticks;           // ... looked for this often (10 ns ticks of s_memrealtime)
     int32_t tail_mode;                    // tier kernel: serve handoff_queue instead of tier 1 of the heavy list
     uint64_t seed_base;
     int32_t nx, ny, ns;

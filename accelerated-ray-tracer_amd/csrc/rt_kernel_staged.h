@@ -90,7 +90,8 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     bool have_pixel = false, first = true, finite_inv = true;
     bool tier3_open = true;      // this lane has not yet seen the end of the tier-3 queue
     bool leave = false;          // tail hand-off (rt_device.h): the frame's last pixels leave for the tail launch at their next sample boundary.  Wave-uniform
-    unsigned int poll_tick = 0, wave_dead = 0;   // ... lanes of this wave counted in work_counter[5]
+    unsigned int wave_dead = 0;  // ... lanes of this wave counted in work_counter[RT_WC_DEAD]
+    unsigned long long last_poll = 0ull;
     bool dry_seen = false;       // a lane of this wave has found its queue empty: from then on the wave looks at the count now and then
     const uint32_t total_lanes = (uint32_t)((int)gridDim.x - rk.main_skip_wgs) * blockDim.x;
     unsigned int rays = 0, rays_at_pixel_start = 0;
@@ -370,12 +371,16 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
             if (n_new > 0 && (n_new >= newpath_need || force || eager)) {
                 ran_stage = true;
                 DIAG_ADD(9, 1); DIAG_ADD(10, n_new);
-                // tail hand-off: once one of its lanes has found its queue empty, a wave looks every 2^k-th time round at how many
-                // lanes of the launch still have work.  The look is a load that misses every cache and stalls the wave: every 8th
-                // time round costs the headline frame 2 ms more than every 64th (profiles/r03_handoff.log).
-                if (fp.handoff_queue && !leave && dry_seen && (++poll_tick & (unsigned)fp.handoff_poll_mask) == 0u) {
-                    const uint32_t dead = __hip_atomic_load(fp.work_counter + RT_WC_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    leave = __builtin_amdgcn_readfirstlane((int)(total_lanes - dead)) <= fp.handoff_pixels;
+                // tail hand-off: once one of its lanes has found its queue empty, a wave looks now and then (option handoff_poll_us)
+                // at how many lanes of the launch still have work.  The look is a load that misses every cache and stalls the
+                // wave: on the headline frame every 8th time round (0.15 ms) cost 2 ms more than every 64th (profiles/r03_handoff.log).
+                if (fp.handoff_queue && !leave && dry_seen) {
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+                    if (now - last_poll >= (unsigned long long)fp.handoff_poll_ticks) {
+                        last_poll = now;
+                        const uint32_t dead = __hip_atomic_load(fp.work_counter + RT_WC_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        leave = __builtin_amdgcn_readfirstlane((int)(total_lanes - dead)) <= fp.handoff_pixels;
+                    }
                 }
                 bool ran_dry = false;      // this lane found its queue empty
                 if (node == ST_NEWPATH) {
