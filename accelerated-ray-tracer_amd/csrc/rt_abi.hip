@@ -71,6 +71,7 @@ struct rt_options {
                                  // the headline frame, nothing on the whole frame or an eighth: profiles/r03_share_sweep_pass2.log)
     int semi_priority = 1;       // s_setprio level of the semi workgroups' waves (tier 3 on workgroups of its own)
     int handoff = 1;             // tail hand-off (rt_device.h): the main kernel's last pixels are finished by a launch of the tier kernel after it
+    int handoff_scan = 1;        // ... also in scenes scanned in lockstep (lds_mode 4), which have no tier 1
     int handoff_poll_us = 1000;  // ... looked for this often by each wave that has run out of queued work
     int handoff_pixels = -1;     // ... when at most this many are in flight and the tile queue is dry; -1 = auto (render_impl)
     int sparse_eager = 0;
@@ -615,6 +616,7 @@ rt_status rt_set_option(const char* key, int value) {
     else if (k == "tier_auto") { if (value < 0 || value > 1) return invalid("tier_auto: 0 or 1"); g_opt.tier_auto = value; }
     else if (k == "tier_kernel") { if (value < 0 || value > 1) return invalid("tier_kernel: 0 or 1"); g_opt.tier_kernel = value; }
     else if (k == "handoff") { if (value < 0 || value > 1) return invalid("handoff: 0 or 1"); g_opt.handoff = value; }
+    else if (k == "handoff_scan") { if (value < 0 || value > 1) return invalid("handoff_scan: 0 or 1"); g_opt.handoff_scan = value; }
     else if (k == "handoff_poll_us") { if (value < 1 || value > 1000000) return invalid("handoff_poll_us: 1..1000000"); g_opt.handoff_poll_us = value; }
     else if (k == "handoff_pixels") { if (value < -1 || value > (1 << 24)) return invalid("handoff_pixels: -1 (auto) or 0..16777216"); g_opt.handoff_pixels = value; }
     else if (k == "prior") { if (value < 0 || value > 1) return invalid("prior: 0 or 1"); g_opt.prior = value; }
@@ -1312,7 +1314,8 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
     fp.tier_lds_scene = 0;
     // (not for scenes scanned in lockstep, lds_mode 4: a handful of leaves, every pixel about as dear as the next -- the Cornell
     // box's 1/8 share measured 182 ms without it and 199 ms with it, profiles/r03_general_defaults.log)
-    if (kernel == RT_KERNEL_STAGED && g_opt.tier_kernel && lds_mode != 4 && s->dev.leaf_lo != nullptr && g_opt.tier1_pixels > 0) {
+    bool tier_fits = false;      // the tier kernel's image fits: enough for the tail launches (tail hand-off) even where tier 1 is not used
+    if (kernel == RT_KERNEL_STAGED && (g_opt.tier_kernel || g_opt.handoff) && s->dev.leaf_lo != nullptr) {
         size_t budget;
         if (lean_family) {
             const size_t used = (size_t)per_cu_resident * (lds_bytes + 512);
@@ -1325,7 +1328,8 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
         }
         const int ns_ = s->dev.n_slots, nsph = s->dev.n_spheres, nm = s->dev.n_materials, nt = s->dev.n_textures;
         if (rt_tier_lds_bytes(ns_, nsph, nm, nt, false) <= budget) {
-            tier_possible = true;
+            tier_fits = true;
+            tier_possible = g_opt.tier_kernel && lds_mode != 4 && g_opt.tier1_pixels > 0;
             if (rt_tier_lds_bytes(ns_, nsph, nm, nt, true) <= budget) fp.tier_lds_scene = 1;
             tier_lds = rt_tier_lds_bytes(ns_, nsph, nm, nt, fp.tier_lds_scene != 0);
             // the tier kernel's grid is fixed before the ranking has sized the tier: what can be resident beside the main
@@ -1337,7 +1341,7 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
     // the tail launch has the machine to itself: as many tier workgroups per CU as registers (launch bounds: 4 resp. 3 waves per SIMD,
     // a workgroup is one wave per SIMD) and LDS hold
     unsigned tail_grid = 0;
-    if (tier_possible && g_opt.handoff) {
+    if (tier_fits && g_opt.handoff && (lds_mode != 4 || g_opt.handoff_scan)) {
         const unsigned by_lds = (unsigned)(g_lds_per_cu / (tier_lds + 512));
         const unsigned by_regs = lean_family ? 4u : 3u;
         tail_grid = (unsigned)g_num_cu * (by_lds < by_regs ? by_lds : by_regs);
@@ -1426,9 +1430,10 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
             fp.handoff_queue = s->d_handoff; fp.handoff_state = s->d_state;
             fp.handoff_poll_ticks = g_opt.handoff_poll_us * 100;
             // auto: six pixels per wave of the tail launch (the headline frame: 18432 of 960000; 8192 .. 32768 measure the same,
-            // profiles/r03_handoff.log), and never more than 1/32 of the pixels (small frames and shares)
+            // profiles/r03_handoff.log), and never more than 1/8 of the pixels (small frames and shares: the Cornell box's
+            // 1/8 share, 45000 pixels, 178 ms without, 163 ms at 4096 - 8192, 180 ms at 16384)
             const size_t tail_waves = (size_t)tail_grid * (RT_TIER_THREADS / 64);
-            const size_t cap_px = n_pixels / 32;
+            const size_t cap_px = n_pixels / 8;
             fp.handoff_pixels = g_opt.handoff_pixels >= 0 ? g_opt.handoff_pixels : (int32_t)(6 * tail_waves < cap_px ? 6 * tail_waves : cap_px);
         }
         // One ranking: three small kernels order the tiles, list the heavy pixels and size the tiers for the launch
