@@ -775,15 +775,30 @@ rt_status build_tier_data(rt_scene* s, const rt_scene_desc* d) {
             const int q = k * 64 + l;
             float* a = &lo[(size_t)q * 4];
             float* b = &hi[(size_t)q * 4];
-            int32_t prim = -1;
+            // lo.w = what a lane tests: the leaf's sphere or quad, for a box (compound6, quad.cuh:124-139) its FIRST face, for an
+            // instance the same of its child; a medium stays itself.  hi.w = instance index + 1 (0 = none) | bit 30: "six faces
+            // from lo.w on" (rt_kernel_tier.h shares those out over six lanes)
+            int32_t prim = -1, xw = 0;
             if (q < m) {
                 for (int c = 0; c < 3; ++c) { a[c] = leaves[q]->bmin[c]; b[c] = leaves[q]->bmax[c]; rl[c] = fminf(rl[c], a[c]); rh[c] = fmaxf(rh[c], b[c]); }
                 prim = leaves[q]->prim;
+                if (RT_PRIM_KIND(prim) == RT_PRIM_INSTANCE) {
+                    const int idx = RT_PRIM_INDEX(prim);
+                    if (idx >= d->n_instances || idx >= (1 << 29)) return RT_OK;   // (rt_scene_create has validated the refs; no tier data otherwise)
+                    xw = idx + 1;
+                    prim = d->instances[idx].child;
+                }
+                if (RT_PRIM_KIND(prim) == RT_PRIM_BOX) {
+                    const int idx = RT_PRIM_INDEX(prim);
+                    if (idx >= d->n_boxes) return RT_OK;
+                    prim = RT_PRIM_REF(RT_PRIM_QUAD, d->boxes[idx].first_quad & 0x3FFFFFFF);
+                    xw |= 1 << 30;
+                }
             } else {
                 for (int c = 0; c < 3; ++c) { a[c] = 0.0f; b[c] = 0.0f; }
             }
             memcpy(&a[3], &prim, 4);
-            b[3] = 0.0f;
+            memcpy(&b[3], &xw, 4);
         }
         for (int c = 0; c < 3; ++c) { ranges[(size_t)k * 8 + c] = rl[c]; ranges[(size_t)k * 8 + 3 + c] = rh[c]; }
     }

@@ -28,8 +28,16 @@ struct TierView {
 };
 
 // minimum over the wave of `v` among the lanes where `have` (bit patterns of non-negative floats order like the floats);
-// FLT_MAX when no lane has one.  The candidates of a ray are few (its hits), so a scalar loop over them is short.
+// FLT_MAX when no lane has one.  Spheres-only scenes: a ray's candidates are few (its hits), a scalar loop over them is short.
+// General scenes: they can be many (every face the ray crosses); a butterfly of six exchanges instead.
+template <bool FEW>
 DEV float wave_min_of(float v, bool have) {
+    if (!FEW) {
+        float r = have ? v : FLT_MAX;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) r = fminf(r, __shfl_xor(r, off, 64));
+        return r;
+    }
     unsigned long long m = __ballot(have);
     float r = FLT_MAX;
     while (m != 0ull) {
@@ -125,34 +133,63 @@ DEV bool trace_wave(const TierView& tv, const SceneView& sc, const Ray& r, HitIn
         }
         if (__ballot(np >= 1) != 0ull) { if (np >= 1) sphere_candidate(p0, o0, e0); }
         if (__ballot(np >= 2) != 0ull) { if (np >= 2) sphere_candidate(p1, o1, e1); }
-    } else
-    while (slot_mask != 0ull) {                    // ascending slots: a lane meets its leaves in ordinal order
+    } else {
+    // General scenes.  A lane's leaf is a sphere or a quad (lo.w), possibly under an instance (hi.w), or a box = compound6
+    // (quad.cuh:124-139: a closest-hit scan over six faces with quad::hit's t <= limit, i.e. six quads that happen to share
+    // one bounding box; lo.w is the first face, bit 30 of hi.w says so).  Boxes are not scanned face after face by the lane
+    // that holds them -- a ray over Book-2 final's ground passes dozens of them, six quad tests each on a few lanes while
+    // the others idle -- but shared out: face f of the T-th passing box of the slot is task 6 T + f, task j runs on lane
+    // j % 64.  A candidate's ordinal is 8 * (leaf ordinal) + face; a lane meets its candidates in no particular order, so it
+    // merges them by the rule that the reduction at the end uses (equal t: the last quad-type one if there is one, else the first).
+    auto candidate = [&](int32_t prim, int32_t inst1, int ord8, float t_enter) {
+        Ray q = r;
+        if (inst1 != 0) q = to_object_space(sc.instances[inst1 - 1], r);
+        float t;
+        const bool is_quad = RT_PRIM_KIND(prim) == RT_PRIM_QUAD;
+        const bool hit = is_quad ? quad_test(sc.quads[RT_PRIM_INDEX(prim)], q, tmin, FLT_MAX, t) : sphere_test(sc.spheres[RT_PRIM_INDEX(prim)], q, tmin, FLT_MAX, t);
+        if (hit) {
+            if (!(t > t_enter)) anomaly = true;
+            const bool better = t < bt || (t == bt && (is_quad ? (!bincl || ord8 > bord) : (!bincl && ord8 < bord)));
+            if (better) { bt = t; bord = ord8; bleaf = prim; binst = inst1 - 1; bincl = is_quad; }
+            if ((ord8 >> 3) < tv.med_ord0) pre0 = fminf(pre0, t);
+            if ((ord8 >> 3) < tv.med_ord1) pre1 = fminf(pre1, t);
+        }
+    };
+    // (Noting the passing leaves of all slots first and running the object tests once per note level instead of once per slot
+    // -- what the spheres-only path does -- measured the same on Book-2 final and 11 % slower on the Cornell box: not kept.)
+    while (slot_mask != 0ull) {
         const int k = __ffsll((long long)slot_mask) - 1;
         slot_mask &= slot_mask - 1ull;
         const int ord = k * 64 + lane;
         const float4 lo4 = tv.lo[ord], hi4 = tv.hi[ord];
-        const int32_t prim = __float_as_int(lo4.w);
+        const int32_t prim = __float_as_int(lo4.w), xw = __float_as_int(hi4.w);
         float t_enter, t_exit;
         slab_interval(lo4, hi4, r.o, inv, tmin, t_enter, t_exit);
-        const bool pass = prim >= 0 && !(t_exit <= t_enter) && (SPHERES_ONLY || RT_PRIM_KIND(prim) != RT_PRIM_MEDIUM);
-        if (__ballot(pass) != 0ull) {
-            if (pass) {
-                float t;
-                int32_t leaf = prim, inst = -1;
-                bool hit;
-                if (SPHERES_ONLY) hit = sphere_test_a(sc.spheres[RT_PRIM_INDEX(prim)], r, a, tmin, FLT_MAX, t);
-                else hit = solid_test(sc, prim, r, tmin, FLT_MAX, t, leaf, inst);
-                if (hit) {
-                    if (!(t > t_enter)) anomaly = true;
-                    const bool incl = !SPHERES_ONLY && RT_PRIM_KIND(leaf) == RT_PRIM_QUAD;
-                    if (t < bt || (incl && t == bt)) { bt = t; bord = ord; bleaf = leaf; binst = inst; bincl = incl; }
-                    if (!SPHERES_ONLY) {
-                        if (ord < tv.med_ord0) pre0 = fminf(pre0, t);
-                        if (ord < tv.med_ord1) pre1 = fminf(pre1, t);
-                    }
+        const bool pass = prim >= 0 && !(t_exit <= t_enter) && RT_PRIM_KIND(prim) != RT_PRIM_MEDIUM;
+        const bool six = (xw & (1 << 30)) != 0;
+        const unsigned long long m1 = __ballot(pass && !six), m6 = __ballot(pass && six);
+        if (m1 != 0ull) { if (pass && !six) candidate(prim, xw & 0x3FFFFFFF, ord * 8, t_enter); }
+        if (m6 != 0ull) {
+            const int need = 6 * __popcll(m6);
+            for (int base = 0; base < need; base += 64) {      // (wave-uniform trip count: one round up to ten boxes)
+                const int j = base + lane;
+                const int T = j / 6, f = j - 6 * T;
+                // the lane holding the T-th passing box: the smallest l with more than T set bits of m6 at or below it
+                int lo_l = 0, hi_l = 63;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int mid = (lo_l + hi_l) >> 1;
+                    const bool enough = __popcll(m6 & ((2ull << mid) - 1ull)) > T;
+                    hi_l = enough ? mid : hi_l;
+                    lo_l = enough ? lo_l : mid + 1;
                 }
+                const int src = lo_l & 63;
+                const int32_t p0 = __shfl(prim, src, 64), x0 = __shfl(xw, src, 64);
+                const float te = __shfl(t_enter, src, 64);
+                if (j < need) candidate(p0 + f, x0 & 0x3FFFFFFF, (k * 64 + src) * 8 + f, te);
             }
         }
+    }
     }
     if (!finite || __ballot(anomaly) != 0ull) return trace<SPHERES_ONLY>(sc, r, best);
     // ---- media, in ordinal order, each against the limit the reference has when it gets there (wave-uniform values)
@@ -161,7 +198,7 @@ DEV bool trace_wave(const TierView& tv, const SceneView& sc, const Ray& r, HitIn
     if (!SPHERES_ONLY) {
         for (int m = 0; m < tv.n_media; ++m) {
             const int ord = m == 0 ? tv.med_ord0 : tv.med_ord1;
-            float limit = wave_min_of(m == 0 ? pre0 : pre1, (m == 0 ? pre0 : pre1) < FLT_MAX);
+            float limit = wave_min_of<false>(m == 0 ? pre0 : pre1, (m == 0 ? pre0 : pre1) < FLT_MAX);
             if (m == 1 && hm[0]) limit = fminf(limit, tm[0]);
             const float4 lo4 = tv.lo[ord], hi4 = tv.hi[ord];               // same address in every lane
             const int32_t prim = __builtin_amdgcn_readfirstlane(__float_as_int(lo4.w));
@@ -175,7 +212,7 @@ DEV bool trace_wave(const TierView& tv, const SceneView& sc, const Ray& r, HitIn
         }
     }
     // ---- the closest candidate; among equal t the last quad-type one in leaf order if there is one, else the first
-    const float ts = wave_min_of(bt, bord >= 0);
+    const float ts = wave_min_of<SPHERES_ONLY>(bt, bord >= 0);
     const float tmin_all = fminf(ts, fminf(tm[0], tm[1]));
     best.inst = -1;
     if (!(tmin_all < FLT_MAX)) { best.t = FLT_MAX; best.prim = -1; return false; }
@@ -195,13 +232,13 @@ DEV bool trace_wave(const TierView& tv, const SceneView& sc, const Ray& r, HitIn
     if (!SPHERES_ONLY) {
         for (int m = 0; m < tv.n_media; ++m) {
             if (!hm[m] || tm[m] != tmin_all) continue;
-            const int o = m == 0 ? tv.med_ord0 : tv.med_ord1;
+            const int o = (m == 0 ? tv.med_ord0 : tv.med_ord1) * 8;      // (candidates' ordinals are 8 * leaf + face)
             if (w_ord < 0 || !w_incl || o > w_ord) { w_ord = o; w_incl = true; w_medium = m; w_lane = -1; }
         }
     }
     best.t = tmin_all;
     if (w_medium >= 0) {
-        const float4 lo4 = tv.lo[w_ord];
+        const float4 lo4 = tv.lo[SPHERES_ONLY ? w_ord : (w_ord >> 3)];       // (general scenes: ordinals are 8 * leaf + face)
         best.prim = __builtin_amdgcn_readfirstlane(__float_as_int(lo4.w));
         return true;
     }
