@@ -355,6 +355,59 @@ def test_split_frame_schedule_matches_oracle(gpu, orc, name, nx, ny, ns):
         assert_frames_equal(fb, ref, f"{name} {opts}")
 
 
+@pytest.mark.parametrize("name,nx,ny,ns", [("bouncing", 160, 96, 16), ("cornell", 96, 96, 12), ("cornell_smoke", 96, 96, 12), ("final", 80, 80, 8),
+                                           ("simple_light", 96, 64, 8)])
+def test_tail_handoff_matches_oracle(gpu, orc, name, nx, ny, ns):
+    """The tail hand-off (rt_device.h: once few pixels are in flight the main kernel parks them at their next sample boundary and a
+    launch of the tier kernel after it finishes them, one per wave) is scheduling only.  Thresholds from "never" to "every pixel,
+    after its first sample", polls from every microsecond to never within the frame, with and without tiers, on a row band: the
+    frame must equal the oracle bit for bit and count the same rays.  The general scenes go through trace_wave's shared-out box
+    faces (Cornell box: two rotated boxes; final: the ground), the lockstep-scanned ones (lds_mode 4) through handoff_scan."""
+    img, iw, ih = gpu.default_texture(name)
+    hs = gpu.HostScene(name, nx, ny, img, iw, ih)
+    ref, cnt = orc.OracleScene(name, nx, ny, img, iw, ih).render(ns)
+    L = gpu.rt_lib()
+    L.rt_debug_handoff.argtypes = [C.c_void_p, C.c_void_p]
+    handed = {}
+    for tag, opts in (("off", {"handoff": 0}), ("auto", {}), ("never", {"handoff_pixels": 0}),
+                      ("all", {"handoff_pixels": 1 << 24, "handoff_poll_us": 1, "split_samples": 4, "presplit_samples": 2}),
+                      ("all, no tiers", {"handoff_pixels": 1 << 24, "handoff_poll_us": 1, "split_samples": 2, "tier_kernel": 0}),
+                      ("all, no prior", {"handoff_pixels": 1 << 24, "handoff_poll_us": 1, "split_samples": 4, "prior": 0}),
+                      ("some", {"handoff_pixels": nx * ny // 4, "handoff_poll_us": 5, "split_samples": 3, "heavy_factor_x10": 12, "tier1_factor_x10": 20, "tier1_pixels": 64}),
+                      ("no scan", {"handoff_scan": 0})):
+        gpu.reset_options()
+        for k, v in opts.items():
+            gpu.set_option(k, v)
+        if any(k.startswith(("tier1_", "heavy_")) for k in opts):
+            gpu.set_option("tier_auto", 0)
+        ds = gpu.DeviceScene(hs)
+        try:
+            fb, st = ds.render(hs.frame(ns=ns))
+            h = np.zeros(2, np.uint64)
+            assert L.rt_debug_handoff(ds._p, h.ctypes.data) == 0
+            handed[tag] = int(h[0])
+        finally:
+            ds.close()
+            gpu.reset_options()
+        assert st.rays == cnt["rays"], (tag, st.rays, cnt["rays"])
+        assert_frames_equal(fb, ref, f"{name} hand-off {tag}")
+    assert handed["off"] == 0 and handed["never"] == 0
+    assert handed["all"] > 0, handed      # the path under test did run
+    # a row band (what one rank of a multi-GPU run renders) with everything handed off
+    gpu.reset_options()
+    gpu.set_option("handoff_pixels", 1 << 24); gpu.set_option("handoff_poll_us", 1); gpu.set_option("split_samples", 4)
+    ds = gpu.DeviceScene(hs)
+    try:
+        f = hs.frame(ns=ns, tile_rows=4, tile_first=1, tile_stride=3)
+        fb, st = ds.render(f)
+    finally:
+        ds.close()
+        gpu.reset_options()
+    rows = gpu.local_rows_to_global(f)
+    assert len(rows) == st.local_rows > 0
+    assert_frames_equal(fb, ref[rows], f"{name} hand-off on a row band")
+
+
 @pytest.mark.parametrize("name,nx,ny", [("bouncing", 96, 64), ("cornell_smoke", 64, 64), ("final", 48, 48)])
 def test_progressive_windows_equal_one_shot(gpu, orc, name, nx, ny):
     """rt_render_window (progressive accumulation on the carried per-pixel RNG state, main.cu:126): windows
