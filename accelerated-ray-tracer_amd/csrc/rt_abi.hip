@@ -1378,6 +1378,10 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
     //     pixel per wave, on a stream of its own beside the main kernel), tier 2 to "sparse" main workgroups with a few live
     //     lanes per wave at raised priority -- a lane's rays advance about twice as fast in a wave with few live lanes --,
     //     tier 3 to ordinary lanes before any tile; ordinary waves skip listed pixels.
+    //   * the end of every part is handed over (rt_device.h, "tail hand-off"): when the tile queue is dry and only a few thousand
+    //     pixels are still in flight, the main kernel's lanes park them at their next sample boundary and a second launch of
+    //     the tier kernel, right behind the main kernel on the same stream, finishes them one per wave -- the last pixels of a
+    //     part are its cheapest ones started last, each still a chain of hundreds of rays at an ordinary lane's pace.
     // The ranking runs on the device (rt_rank.hip) and leaves the tier sizes in device memory, so the whole frame is
     // enqueued without a host round trip.  Scheduling only: every sample of every pixel is rendered exactly once, in
     // its pixel's stream order; frames are bit-identical with and without it (tests sweep the knobs).

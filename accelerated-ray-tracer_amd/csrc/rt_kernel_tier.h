@@ -7,6 +7,8 @@
 // with all 64 lanes (trace_wave below), which makes a ray several times faster than on a lane of the main kernel's
 // state machine.  Every lane of a wave carries the same pixel and computes the same values; only the traversal is
 // shared out.  The reference's loop nest (main.cu:107-133, color() main.cu:44-87) is otherwise kept as it stands.
+// A second kind of launch (fp.tail_mode) follows every main-kernel launch: it serves the queue of pixels the main kernel
+// handed off near its end (rt_device.h, "tail hand-off"), each from the sample and the state its lane left it with.
 //
 // Why its own kernel (round 3): inside the main kernel the one-pixel loops cost every ordinary wave their register
 // budget (128 VGPRs + 112 B of scratch instead of 94 + 0, profiles/r03_kernel_resources.md), and a general-scene
