@@ -64,7 +64,12 @@ out["kernel_ms_per_step_traced"] = round(sum(durs) / frames, 3)
 out["dispatch_ms"] = [round(x, 3) for x in durs[-per:]]
 out["vgpr_count"] = rows[-1].get("VGPR_Count")
 if tier_rows:
-    out["tier_dispatch_ms"] = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 3) for r in tier_rows[-per:]]
+    # the tier kernel's launches of the last frame, in start order: per ranked part one beside the main kernel (tier 1) and one
+    # behind it (the tail launch) -- told apart by their grids
+    t_first = int(rows[-per]["Start_Timestamp"]) - 1000000
+    last = sorted((r for r in tier_rows if int(r["Start_Timestamp"]) >= t_first), key=lambda r: int(r["Start_Timestamp"]))
+    out["tier_dispatch_ms"] = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 3) for r in last]
+    out["tier_dispatch_workgroups"] = [int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) // max(int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 1)) or 1), 1) for r in last]
     out["tier_vgpr_count"] = tier_rows[-1].get("VGPR_Count")
 counters = {}
 for sub in ("pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_fetch", "pmc_write"):
