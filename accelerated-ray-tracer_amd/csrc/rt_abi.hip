@@ -1318,8 +1318,8 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
         fp.newpath_threshold = g_opt.newpath_threshold > 0 ? g_opt.newpath_threshold : (s->spheres_only ? (latency_regime ? 12 : 24) : 8);
     }
     // ---- the tier kernel of ranked launches (rt_kernel_tier.h): its LDS image and where its workgroups find room.
-    // Lean family: the main kernel's 4 x 96 registers per SIMD leave 128 free, so ONE tier workgroup (four waves, one per
-    // SIMD, <= 128 VGPRs) is resident on a CU beside a full main grid if the LDS left over holds its image.  Other families:
+    // Lean family: the main kernel's 4 x 104 registers per SIMD leave 96 free, so ONE tier workgroup (four waves, one per
+    // SIMD, 76 VGPRs) is resident on a CU beside a full main grid if the LDS left over holds its image.  Other families:
     // no register room beside a full main grid; the ranking makes main workgroups leave (main_skip_wgs) and a tier workgroup
     // has what one of them had.  The image always holds the leaf arrays; spheres, materials and textures too where all of them fit.
     bool tier_possible = false;

@@ -9,9 +9,10 @@
 #define RT_PERSISTENT_THREADS 512   // default workgroup size of the staged kernel
 // Register budgets of the staged kernel families, as launch bounds (threads per workgroup the code may be launched
 // with, waves per SIMD it must leave room for).  "Lean" = spheres-only scenes without procedural / image textures (the
-// headline kernel): 94 VGPRs, no scratch (profiles/r03_kernel_resources.md) -- the double-precision transcendentals are out
-// of line and the one-pixel-per-wave loops live in their own kernel (rt_kernel_tier.h).  It is launched 2 x 512 threads per
-// CU = 4 waves per SIMD: 4 x 96 registers leave 128 of a SIMD's 512 for one co-resident wave of the tier kernel.
+// headline kernel): 97 VGPRs (allocated in eights: 104), no scratch (profiles/r03_kernel_resources.md) -- the double-precision
+// transcendentals are out of line and the one-pixel-per-wave loops live in their own kernel (rt_kernel_tier.h).  It is launched
+// 2 x 512 threads per CU = 4 waves per SIMD: 4 x 104 registers leave 96 of a SIMD's 512 for one co-resident wave of the tier
+// kernel (76, allocated 80).  104 is therefore this kernel's ceiling, not the 128 the launch bounds would allow.
 // Everything else (quads / boxes / media, Perlin / image textures) is budgeted 168 VGPRs: 3 waves per SIMD.
 #ifndef RT_LEAN_MIN_WAVES
 #define RT_LEAN_MIN_WAVES 4
@@ -22,8 +23,8 @@
 #define RT_HEAVY_MAX_THREADS 768
 #define RT_HEAVY_MIN_WAVES 3
 
-// the tier kernel (rt_kernel_tier.h): workgroups of four waves, one per SIMD; <= 128 VGPRs for the lean family (co-resident
-// with the main kernel's 4 x 96), 168 for the others (its workgroups take the slots main workgroups vacate: main_skip_wgs)
+// the tier kernel (rt_kernel_tier.h): workgroups of four waves, one per SIMD; the lean family's must fit beside the main kernel's
+// 4 x 104 registers per SIMD (they take 76), the others get 168 (their workgroups take the slots main workgroups vacate: main_skip_wgs)
 #define RT_TIER_THREADS 256
 // kernel ids keep their round-1 numbers (1 = persistent, 2 = parked, 4 = wavefront were experiments; removed)
 // the statistics block behind rt_frame_params.ray_counter (64-bit words): [0] rays, [1..16] stage counters and [32..] the

@@ -13,7 +13,7 @@
 // Why its own kernel (round 3): inside the main kernel the one-pixel loops cost every ordinary wave their register
 // budget (128 VGPRs + 112 B of scratch instead of 94 + 0, profiles/r03_kernel_resources.md), and a general-scene
 // version (quads, boxes, instances, media; up to 4096 leaves) would not have fitted at all.  Workgroups are four waves,
-// one per SIMD.  The lean family's main kernel leaves 128 registers per SIMD free (4 x 96 of 512), so a tier workgroup
+// one per SIMD.  The lean family's main kernel leaves 96 registers per SIMD free (4 x 104 of 512), so a tier workgroup (76)
 // is co-resident with a full main grid; for the other families the first main_skip_wgs main workgroups leave at once
 // and the tier workgroups take their slots (tools/ubench/concurrent_kernels.hip measures both cases).
 #pragma once
