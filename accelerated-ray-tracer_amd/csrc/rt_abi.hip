@@ -1446,7 +1446,7 @@ static rt_status render_impl(rt_scene* s, const rt_frame_desc* f, float* fb, int
                 HIPCHK(hipMalloc((void**)&s->d_handoff, lanes * sizeof(unsigned long long)));
                 s->handoff_capacity = lanes;
             }
-            fp.handoff_queue = s->d_handoff; fp.handoff_state = s->d_state;
+            fp.handoff_queue = s->d_handoff; fp.handoff_cap = (uint32_t)s->handoff_capacity; fp.handoff_state = s->d_state;
             fp.handoff_poll_ticks = g_opt.handoff_poll_us * 100;
             // auto: six pixels per wave of the tail launch (the headline frame: 18432 of 960000; 8192 .. 32768 measure the same,
             // profiles/r03_handoff.log), and never more than 1/8 of the pixels (small frames and shares: the Cornell box's

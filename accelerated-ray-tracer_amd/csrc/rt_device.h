@@ -152,6 +152,7 @@ struct rt_frame_params {
     // them one pixel per wave.  Its counters live in a cache line of their own, away from the queue heads at work_counter[0..4]: with
     // the polled word in the queue heads' line every pixel fetch of the frame slowed down (headline 96 -> 118 ms).
     unsigned long long* handoff_queue;    // null = no hand-off
+    uint32_t handoff_cap;                 // its entries
     rt_pixel_state* handoff_state;
     int32_t handoff_pixels;
     int32_t handoff_poll_ticks;           // ... looked for this often (10 ns ticks of s_memrealtime)

@@ -388,8 +388,13 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                     first = false;
                     bool alive = true;
                     const bool part_done = sample >= fp.sample_end;
-                    if (have_pixel && (part_done || leave)) {
-                        const bool hand = !part_done;      // samples [sample, sample_end) go to the tail launch
+                    // hand-off: samples [sample, sample_end) go to the tail launch.  The lane takes a slot of the queue first; the queue has
+                    // one per resident lane, which a lane exceeds only if its wave turns ordinary again and again with the threshold set
+                    // absurdly high -- a lane that finds the queue full keeps its pixel
+                    bool hand = have_pixel && !part_done && leave;
+                    uint32_t slot = 0u;
+                    if (hand) { slot = atomicAdd(fp.work_counter + RT_WC_PUSHED, 1u); hand = slot < fp.handoff_cap; }
+                    if (have_pixel && (part_done || hand)) {
                         if (fp.state_out || hand) {
                             // first part of a split frame: park the pixel at this sample boundary (no path is in flight
                             // here, so the XORWOW state and the colour sum are the whole state) and record what it cost
@@ -402,7 +407,6 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
                             (hand ? fp.handoff_state : fp.state_out)[at] = st;
                             if (fp.tile_cost) atomicAdd(&fp.tile_cost[(px_lrow >> 3) * fp.tiles_x + (px_i >> 3)], c);
                             if (hand) {
-                                const uint32_t slot = atomicAdd(fp.work_counter + RT_WC_PUSHED, 1u);
                                 fp.handoff_queue[slot] = ((unsigned long long)(uint32_t)sample << 32) | (unsigned long long)at;
                                 alive = false;
                             } else if (fp.store_parked) store_pixel(fp, px_i, px_lrow, col);   // a progressive window: the frame so far

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(RT_TIER_THREADS, (SPHERES_ONLY && TEX < 2) ? 4
     // tail_mode: the launch after the main kernel that finishes the pixels it handed off (rt_device.h, "tail hand-off")
     const bool tail = (fp.tail_mode & 1) != 0;
     const rt_rank_info* q = fp.rank;
-    const uint32_t n_items = tail ? fp.work_counter[RT_WC_PUSHED] : q->tier1_items;
+    const uint32_t n_items = tail ? (fp.work_counter[RT_WC_PUSHED] < fp.handoff_cap ? fp.work_counter[RT_WC_PUSHED] : fp.handoff_cap) : q->tier1_items;   // (slots taken beyond the queue's end were not filled)
     const int my_wgs = tail ? (int)((n_items + RT_TIER_THREADS / 64 - 1) / (RT_TIER_THREADS / 64)) : q->tier1_wgs;
     if ((int)blockIdx.x >= my_wgs) return;        // the grid is fixed before the ranking has sized the tier
     // these waves are the frame's critical path: they win instruction-issue arbitration on their SIMD (option tier_priority)

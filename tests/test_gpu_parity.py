@@ -435,3 +435,29 @@ def test_progressive_windows_equal_one_shot(gpu, orc, name, nx, ny):
         prog.close()
     finally:
         ds.close()
+
+
+def test_tail_handoff_queue_cannot_overflow(gpu):
+    """The hand-off queue holds one entry per resident lane.  With the threshold set absurdly high on a frame of more pixels than
+    lanes (960 000 against 262 144), waves that turn ordinary again fetch and hand off over and over: lanes that find the queue
+    full must keep their pixels.  The frame equals the one rendered without a hand-off, bit for bit, and counts the same rays."""
+    nx, ny, ns = 1200, 800, 64
+    hs = gpu.HostScene("random_scene", nx, ny)
+    base, st0 = render(gpu, hs, DEFAULT_KERNEL, {"handoff": 0}, ns=ns)
+    L = gpu.rt_lib()
+    L.rt_debug_handoff.argtypes = [C.c_void_p, C.c_void_p]
+    for opts in ({"handoff_pixels": 1 << 24, "handoff_poll_us": 1}, {"handoff_pixels": 1 << 24, "handoff_poll_us": 1, "sparse_wg_percent": 100, "heavy_factor_x10": 10, "tier_auto": 0}):
+        gpu.reset_options()
+        for k, v in opts.items():
+            gpu.set_option(k, v)
+        ds = gpu.DeviceScene(hs)
+        try:
+            fb, st = ds.render(hs.frame(ns=ns))
+            h = np.zeros(2, np.uint64)
+            assert L.rt_debug_handoff(ds._p, h.ctypes.data) == 0
+        finally:
+            ds.close()
+            gpu.reset_options()
+        assert st.rays == st0.rays, (opts, st.rays, st0.rays)
+        assert np.array_equal(fb.view(np.uint32), base.view(np.uint32)), opts
+        assert int(h[0]) > 0, opts
