@@ -50,12 +50,14 @@ struct rt_options {
     int medium_threshold = 16;
     int newpath_threshold = 0;   // lanes waiting for a new path before stage E runs; 0 = by kernel family: 24 spheres-only, 8 general (measured: Book-2 final 382 -> 364 ms with 8, Book-1 32.2 -> 35.1)
     int sparse_stride = 8;      // lanes per pixel in sparse waves (64 / live lanes); 0 disables sparse waves
-    int split_samples = 32;      // samples per pixel rendered before pixels are ranked by measured cost
+    int split_samples = 16;      // samples per pixel rendered before pixels are ranked by measured cost (round 3: 16 and no presplit -- two parts; was 32 after a first look at 8)
     int tier_auto = 1;           // size the tiers from the share of the frame this call renders (see rank_pixels); 0 = the knobs as set
     int tier_kernel = 1;         // tier 1 of the list goes to the tier kernel (rt_kernel_tier.h) on a side stream; 0 = no tier 1
     int prior = 1;               // the first part of a split frame is already ranked: on the cost prior of the calibration frame
     int resplit_samples = 0;     // a second ranking: samples [split, resplit) run with tiers ranked on `split` samples, the rest ranked on `resplit` (0 = off)
-    int presplit_samples = 8;    // a first, shorter look: samples [presplit, split) already run with tiers ranked on it (0 = off)
+    int presplit_samples = 0;    // a first, shorter look: samples [presplit, split) already run with tiers ranked on it (0 = off).  Off since the
+                                 // cost prior ranks the first part: [0,16) + [16,ns) is as fast or faster than [0,8) + [8,32) + [32,ns) on every
+                                 // BASELINE frame and 10 % faster at 100 spp (profiles/r03_two_parts.log)
     int tier1_factor_x10 = 45;   // tier 1 = heavy pixels costing >= this/10 x the mean
     int tier1_pixels = 1536;     // heavy pixels served one per wave at a time (tier 1)
     int cost_smooth_percent = 0;  // ranking: a pixel's cost estimate is at least this share of its dearest 4-neighbour's (0 = own cost only)

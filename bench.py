@@ -105,7 +105,7 @@ def roofline(scene, nx, ny, ns, rays_step, kernel_ms, frame_rays=None):
          "hbm": hbm,
          "pmc_record": f"profiles/pmc_{key}.json", "pmc_record_is_of_this_build": rec.get("csrc_sha1") == h.hexdigest()[:16],
          "share_of_the_record_frame": round(share, 4),
-         "note": "instruction and byte counts per step come from the committed PMC record (rocprofv3 passes of this bench command); the time is this run's: the launches of the render kernel for one frame (three with the cost-aware schedule) plus the ranking kernels between them, HIP events on the launch stream"}
+         "note": "instruction and byte counts per step come from the committed PMC record (rocprofv3 passes of this bench command); the time is this run's: the launches of the render kernels for one frame (with the cost-aware schedule two of the main kernel, each with a tier-kernel launch beside and behind it) plus the ranking kernels between them, HIP events on the launch stream"}
     return r
 
 

@@ -1,7 +1,7 @@
 """The configuration that ships, at the sizes BASELINE.json quotes, against the oracle.
 
-Every test here runs with the library's default options (rt_reset_options: the cost-aware three-launch schedule with
-split 32 / presplit 8, automatic tier sizing, device-side ranking) -- exactly what bench.py times -- and compares fp32
+Every test here runs with the library's default options (rt_reset_options: the cost-aware schedule -- samples
+[0, 16) ranked on the cost prior, [16, ns) on measured costs --, automatic tier sizing, device-side ranking, tail hand-off) -- exactly what bench.py times -- and compares fp32
 bits with the CPU oracle on row bands (a whole 1200x800 @ 500 frame is 1.0e9 rays; a band of 8 rows is ~1e7, seconds
 on the host), plus the ray counts of those bands.  Reference path: render_init + render, src/main.cu:96-133.
 """

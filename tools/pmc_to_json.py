@@ -2,8 +2,8 @@
 """Turns a tools/profile_bench.sh output directory into the per-step counter record bench.py reads for its roofline
 object.  Usage: pmc_to_json.py gpurun_out/prof_<tag> <workload key> [frames]  > profiles/pmc_<key>.json
 
-Per step (= one frame = every dispatch of the main kernel and of the tier kernel for that frame: three each with the cost-aware
-schedule) it sums, over those dispatches of each rocprofv3 pass, and divides by the number of frames in the pass (= main-kernel
+Per step (= one frame = every dispatch of the main kernel and of the tier kernel for that frame: with the cost-aware schedule
+two of the main kernel, each with a tier-1 launch beside it and a tail launch behind it) it sums, over those dispatches of each rocprofv3 pass, and divides by the number of frames in the pass (= main-kernel
 dispatches / dispatches per step; counter passes serialise the kernels, so the two never share a counter window):
   SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU, SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, SQ_WAIT_ANY, SQ_WAIT_INST_ANY,
   SQ_ACTIVE_INST_ANY, SQ_INSTS_LDS, SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT, SQ_INSTS_SALU, GRBM_GUI_ACTIVE,
@@ -56,7 +56,9 @@ rows = [r for r in all_rows if KERNEL in r["Kernel_Name"]]
 tier_rows = [r for r in all_rows if "rt_tier_kernel" in r["Kernel_Name"]]
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
 # dispatches per frame: a frame's last dispatch is its longest; frames = count of local maxima pattern -> use the argument or infer 3 / 1
-per = int(sys.argv[3]) if len(sys.argv) > 3 else (3 if len(durs) % 3 == 0 and len(durs) >= 3 and durs[2] > 4 * durs[0] else 1)
+# (a frame's last launch is by far its longest: launches per frame = launches / launches at least half as long as the longest)
+long_ones = sum(1 for x in durs if x >= 0.5 * max(durs))
+per = int(sys.argv[3]) if len(sys.argv) > 3 else (len(durs) // long_ones if long_ones and len(durs) % long_ones == 0 else 1)
 frames = len(durs) // per
 out["dispatches_per_step"] = per
 out["frames_profiled"] = frames
