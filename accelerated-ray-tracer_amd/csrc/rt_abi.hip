@@ -820,6 +820,19 @@ rt_status build_tier_data(rt_scene* s, const rt_scene_desc* d) {
     return RT_OK;
 }
 
+// A walk array this small is not walked but scanned in lockstep (lds_mode 4): every lane of a wave steps through every node
+// whatever its own boxes said, so an interior node can only cost.  The leaves alone, in their order, are the array then (the
+// Cornell box: 11 -> 8 nodes).  Returns whether `walk` was replaced.
+bool leaves_only_if_scanned(const rt_node* src, int m, std::vector<rt_node>& walk) {
+    if (g_opt.scan_nodes <= 0 || m > g_opt.scan_nodes) return false;
+    std::vector<rt_node> leaves;
+    for (int i = 0; i < m; ++i)
+        if (src[i].prim >= 0) { rt_node w = src[i]; w.skip = (int32_t)leaves.size() + 1; leaves.push_back(w); }
+    if (leaves.empty() || (int)leaves.size() >= m) return false;
+    walk.swap(leaves);
+    return true;
+}
+
 // builds the walk array (see "Collapse" above) and points dev.nodes at it
 rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
     const int n = d->n_nodes;
@@ -879,6 +892,10 @@ rt_status build_walk(rt_scene* s, const rt_scene_desc* d) {
                 changed = true;
             }
         }
+    }
+    {   // (the estimates stay the plan's: per-lane box tests of the array a walk would use)
+        std::vector<rt_node> cur = changed ? walk : std::vector<rt_node>(d->nodes, d->nodes + n);
+        if (leaves_only_if_scanned(cur.data(), (int)cur.size(), walk)) changed = true;
     }
     if (!changed) return RT_OK;
     const rt_node* d_walk = nullptr;

@@ -94,7 +94,9 @@ def test_calibration_pass_counts_are_the_oracles(gpu, orc, name, ny):
     passes, rays, box_tests = o.node_passes(4, threads=8)
     assert abs(info["tests_before"] * rays - box_tests) < 0.5, (info["tests_before"] * rays, box_tests)
     walk, before, after = gpu.plan_walk_array(hs.nodes(), passes, rays)
-    assert len(walk) == info["nodes_walked"], (len(walk), info)
+    # (an array small enough to be scanned in lockstep -- option scan_nodes, 24 -- is reduced to its leaves after planning)
+    expect = int((walk["prim"] >= 0).sum()) if len(walk) <= 24 else len(walk)
+    assert expect == info["nodes_walked"], (len(walk), expect, info)
     assert abs(after - info["tests_after"]) < 1e-9 * max(1.0, after)
 
 
@@ -126,7 +128,8 @@ def test_walk_array_is_invisible(gpu, orc, name, nx, ny, ns):
         n_leaves = int((hs.nodes()["prim"] >= 0).sum())
         assert n_leaves <= info["nodes_walked"] <= info["nodes_reference"]
         if mode and info["nodes_walked"] < info["nodes_reference"]:
-            assert info["tests_after"] < info["tests_before"]
+            # (<=: an array small enough to be scanned in lockstep is reduced to its leaves even where the planner kept every node)
+            assert info["tests_after"] <= info["tests_before"]
     assert sizes[0] == hs.desc.n_nodes
     print(name, sizes)
 
