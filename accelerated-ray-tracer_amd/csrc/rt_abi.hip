@@ -822,7 +822,7 @@ rt_status build_tier_data(rt_scene* s, const rt_scene_desc* d) {
 
 // A walk array this small is not walked but scanned in lockstep (lds_mode 4): every lane of a wave steps through every node
 // whatever its own boxes said, so an interior node can only cost.  The leaves alone, in their order, are the array then (the
-// Cornell box: 11 -> 8 nodes).  Returns whether `walk` was replaced.
+// Cornell box: 11 -> 10 nodes).  Returns whether `walk` was replaced.
 bool leaves_only_if_scanned(const rt_node* src, int m, std::vector<rt_node>& walk) {
     if (g_opt.scan_nodes <= 0 || m > g_opt.scan_nodes) return false;
     std::vector<rt_node> leaves;

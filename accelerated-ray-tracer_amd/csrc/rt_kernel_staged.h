@@ -51,7 +51,7 @@ __global__ void __launch_bounds__((SPHERES_ONLY && TEX < 2) ? RT_LEAN_MAX_THREAD
     unsigned long long diag_fetch_t = 0ull, diag_done_t = 0ull;   // when this lane took its last pixel / ran out of work
     unsigned int diag_last_px = 0u, diag_last_src = 0u;          // that pixel, and where it came from (0 tile, 2 sparse list, 3 tier 3)
 #endif
-    // LDS_MODE 4 = "scan": a scene of a few nodes (Cornell box: 11 after the collapse) is not walked lane by lane.  All
+    // LDS_MODE 4 = "scan": a scene of a few nodes (Cornell box: its 10 leaves, rt_abi.hip leaves_only_if_scanned) is not walked lane by lane.  All
     // lanes that have a ray go through the depth-first array together, node by node; node and object records have
     // wave-uniform addresses (scalar cache, no LDS), the object kind is a scalar branch, and a lane only carries the index
     // below which it skips (a failed interior box).  Same tests against the same limits in the same order as the walk.
